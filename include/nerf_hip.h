@@ -1,0 +1,172 @@
+/*
+ * nerf_hip.h -- C ABI of libnerf_hip.so, the MI355X (gfx950) implementation of
+ * the NeRF render path.
+ *
+ * The reference (hadleyhzy34/nerf) has no FFI: its boundary is the Python call
+ * surface of src/nerf_project/models/nerf.py and utils/ray_utils.py.  Each
+ * entry point below names the reference lines whose arithmetic it replaces;
+ * the Python package nerf_amd binds these symbols with ctypes and re-exposes
+ * the reference's own signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless a comment says "host";
+ *   - tensors are fp32, row-major, contiguous unless a stride is given;
+ *   - the caller owns every buffer (inputs, outputs, workspaces); nothing is
+ *     allocated, freed or retained by the library;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and
+ *     the call returns without synchronising;
+ *   - return value: 0 = ok, negative = NERF_E_* argument error (nothing was
+ *     launched), positive = a hipError_t from the launch.
+ *   - entry points are re-entrant and keep no mutable global state.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_HIP_VERSION 100 /* 0.1.0 */
+
+enum {
+    NERF_OK = 0,
+    NERF_E_NULL = -1,      /* a required pointer is NULL            */
+    NERF_E_SHAPE = -2,     /* a size is out of the supported range  */
+    NERF_E_ALIGN = -3,     /* a pointer misses its required alignment */
+    NERF_E_ARCH = -4,      /* unsupported network architecture      */
+    NERF_E_WORKSPACE = -5, /* workspace too small                   */
+    NERF_E_DTYPE = -6      /* unknown precision selector            */
+};
+
+/* precision selector of the MLP kernels (operand type; accumulation is fp32) */
+enum { NERF_PREC_BF16 = 0, NERF_PREC_FP16 = 1 };
+
+int nerf_version(void);
+const char *nerf_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * get_rays -- src/nerf_project/utils/ray_utils.py:38-65.
+ * Rows [row0, row0+nrows) of an H x W pinhole frame.  c2w: 12 floats (the
+ * top 3x4 of the pose, row stride c2w_ld = 4).  rays_o, rays_d: [nrows, W, 3].
+ */
+int nerf_get_rays(int H, int W, float focal, const float *c2w, int c2w_ld, int row0, int nrows,
+                  float *rays_o, float *rays_d, void *stream);
+
+/* ------------------------------------------------------------------------
+ * stand-alone positional encoding -- models/nerf.py:68-76.
+ * x [n, d] -> out [n, d*(1+2L)] = [x, sin(f0 x), cos(f0 x), ...]; freqs: L floats
+ * (the module's freq_bands buffer).
+ */
+int nerf_posenc(int64_t n, int d, int L, const float *freqs, const float *x, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * sample placement -- models/nerf.py:373-402.
+ * z_out [n_rays, S].  z_override (nullable) replaces the linspace in depth
+ * (lindisp = 0) or disparity (lindisp = 1) between near and far; near_ray /
+ * far_ray (nullable, [n_rays]) override the scalars.  t_rand (nullable,
+ * [n_rays, S] uniforms in [0,1)) applies the stratified jitter of :393-402.
+ */
+int nerf_place_samples(int64_t n_rays, int S, float near_s, float far_s, const float *near_ray,
+                       const float *far_ray, int lindisp, const float *z_override, const float *t_rand,
+                       float *z_out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * alpha compositing forward -- models/nerf.py:430-472.
+ * raw [n_rays,S,4] (16-byte aligned), z [n_rays,S] ->
+ * rgb_map [n_rays,3], depth/disp/acc [n_rays], weights [n_rays,S],
+ * alpha [n_rays,S] (nullable).  1 <= S <= 1024.
+ */
+int nerf_composite_fwd(int64_t n_rays, int S, const float *raw, const float *z, int white_bkgd,
+                       float *rgb_map, float *depth_map, float *disp_map, float *acc_map, float *weights,
+                       float *alpha, void *stream);
+
+/* alpha compositing backward (the autograd of models/nerf.py:430-472).
+ * Cotangents (each nullable = zero): g_rgb [n_rays,3], g_depth, g_disp, g_acc
+ * [n_rays], g_weights, g_alpha [n_rays,S].  Output d_raw [n_rays,S,4].
+ * The forward quantities are recomputed from raw and z.
+ */
+int nerf_composite_bwd(int64_t n_rays, int S, const float *raw, const float *z, int white_bkgd,
+                       const float *g_rgb, const float *g_depth, const float *g_disp, const float *g_acc,
+                       const float *g_weights, const float *g_alpha, float *d_raw, void *stream);
+
+/* ------------------------------------------------------------------------
+ * sample_pdf -- models/nerf.py:237-313.
+ * bins [n_rays, n_bins] (row stride bins_ld), weights [n_rays, n_bins-1]
+ * (row stride w_ld); u (nullable) [n_rays, n_samples] uniforms, NULL =
+ * deterministic linspace(0,1,n_samples).  samples [n_rays, n_samples];
+ * inds (nullable) [n_rays, n_samples] = searchsorted(cdf, u, right) of :262.
+ * 2 <= n_bins <= 1024.
+ */
+int nerf_sample_pdf(int64_t n_rays, int n_bins, const float *bins, int64_t bins_ld, const float *weights,
+                    int64_t w_ld, int n_samples, const float *u, float *samples, int32_t *inds,
+                    void *stream);
+
+/* Coarse->fine glue -- scripts/train_nerf.py:309-320 (= render_nerf.py:288-294):
+ * bins = midpoints of z_coarse, weights = w_coarse[1:-1] + 1e-5, sample_pdf,
+ * then the ascending sort of cat(z_coarse, z_fine).
+ * z_coarse, w_coarse [n_rays, Sc]; u nullable [n_rays, n_fine];
+ * z_out [n_rays, Sc + n_fine]; z_fine_out nullable [n_rays, n_fine].
+ * 3 <= Sc <= 1024, Sc + n_fine <= 1024.
+ */
+int nerf_sample_merge(int64_t n_rays, int Sc, const float *z_coarse, const float *w_coarse, int n_fine,
+                      const float *u, float *z_out, float *z_fine_out, void *stream);
+
+/* Row-wise ascending sort of cat(a[r], b[r]) -- the torch.sort(torch.cat(..))
+ * of scripts/train_nerf.py:320.  b nullable (n_b = 0).  n_a + n_b <= 1024. */
+int nerf_sort_rows(int64_t n_rows, int n_a, const float *a, int n_b, const float *b, float *out,
+                   void *stream);
+
+/* ------------------------------------------------------------------------
+ * Fused positional encoding + MLP -- models/nerf.py:68-76 (PositionalEncoder,
+ * L=10 for points, L=4 for view directions, frequencies 2^l, no pi) and
+ * models/nerf.py:173-209 (NeRF.forward, D=8, W=256, skips=[4], use_viewdirs).
+ *
+ * The network is described by a flat fp32 parameter buffer in state_dict
+ * order (pts_linears.0.weight, pts_linears.0.bias, ..., rgb_layers.2.bias;
+ * 595 844 floats).  nerf_mlp_pack converts it once per weight update into
+ * the MFMA fragment streams the kernels read.
+ */
+#define NERF_MLP_NPARAMS 595844
+
+/* bytes of the packed-weight buffer (forward + transposed streams + biases) */
+int64_t nerf_mlp_packed_bytes(void);
+
+/* params: flat fp32 [NERF_MLP_NPARAMS]; packed: nerf_mlp_packed_bytes() bytes, 256-byte aligned. */
+int nerf_mlp_pack(const float *params, int precision, void *packed, void *stream);
+
+/* bytes of activations the training forward saves per sample (for nerf_mlp_bwd) */
+int64_t nerf_mlp_saved_bytes(int64_t n_samples);
+/* bytes of workspace nerf_mlp_bwd needs */
+int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples);
+
+/* Forward.  Sample m = ray*S + k sits at rays_o[ray] + rays_d[ray] * z[ray,k]
+ * with view direction rays_d[ray] / |rays_d[ray]| (models/nerf.py:409-421).
+ * raw [n_rays*S, 4] = (rgb_raw, sigma_raw), 16-byte aligned.
+ * saved (nullable): nerf_mlp_saved_bytes(n_rays*S) bytes; when given, the
+ * hidden activations are kept for nerf_mlp_bwd.
+ */
+int nerf_mlp_fwd(int64_t n_rays, int S, const float *rays_o, const float *rays_d, const float *z,
+                 const void *packed, int precision, float *raw, void *saved, void *stream);
+
+/* Forward on pre-encoded inputs (the literal NeRF.forward signature):
+ * x_pts [M,63], x_views [M,27] fp32. */
+int nerf_mlp_fwd_encoded(int64_t M, const float *x_pts, const float *x_views, const void *packed,
+                         int precision, float *raw, void *saved, void *stream);
+
+/* Backward: d_raw [M,4] -> d_params flat fp32 [NERF_MLP_NPARAMS] (overwritten,
+ * not accumulated).  saved is what nerf_mlp_fwd wrote for the same samples. */
+int nerf_mlp_bwd(int64_t M, const float *d_raw, const void *packed, int precision, const void *saved,
+                 void *workspace, int64_t workspace_bytes, float *d_params, void *stream);
+
+/* Adam on a flat fp32 buffer -- the optimizer.step() of scripts/train_nerf.py:336
+ * (torch.optim.Adam, no weight decay, no amsgrad).  step is 1-based. */
+int nerf_adam_step(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                   float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

@@ -1,0 +1,62 @@
+"""ctypes binding of libnerf_hip.so (the C ABI declared in include/nerf_hip.h).
+
+There is no fallback: if the library has not been built, importing this module
+raises, and every wrapper raises on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnerf_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP library first "
+        "(`make -C nerf_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "nerf_amd has no CPU or PyTorch fallback."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+P = c_void_p
+_SIGS = {
+    "nerf_version": (c_int, []),
+    "nerf_error_string": (c_char_p, [c_int]),
+    "nerf_get_rays": (c_int, [c_int, c_int, c_float, P, c_int, c_int, c_int, P, P, P]),
+    "nerf_posenc": (c_int, [c_int64, c_int, c_int, P, P, P, P]),
+    "nerf_place_samples": (c_int, [c_int64, c_int, c_float, c_float, P, P, c_int, P, P, P, P]),
+    "nerf_composite_fwd": (c_int, [c_int64, c_int, P, P, c_int, P, P, P, P, P, P, P]),
+    "nerf_composite_bwd": (c_int, [c_int64, c_int, P, P, c_int, P, P, P, P, P, P, P, P]),
+    "nerf_sample_pdf": (c_int, [c_int64, c_int, P, c_int64, P, c_int64, c_int, P, P, P, P]),
+    "nerf_sample_merge": (c_int, [c_int64, c_int, P, P, c_int, P, P, P, P]),
+    "nerf_sort_rows": (c_int, [c_int64, c_int, P, c_int, P, P, P]),
+    "nerf_mlp_packed_bytes": (c_int64, []),
+    "nerf_mlp_pack": (c_int, [P, c_int, P, P]),
+    "nerf_mlp_saved_bytes": (c_int64, [c_int64]),
+    "nerf_mlp_bwd_workspace_bytes": (c_int64, [c_int64]),
+    "nerf_mlp_fwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P, P]),
+    "nerf_mlp_fwd_encoded": (c_int, [c_int64, P, P, P, c_int, P, P, P]),
+    "nerf_mlp_bwd": (c_int, [c_int64, P, P, c_int, P, P, c_int64, P, P]),
+    "nerf_adam_step": (c_int, [c_int64, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header and library disagree
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+SYMBOLS = tuple(_SIGS)
+NERF_MLP_NPARAMS = 595844
+PREC = {"bf16": 0, "fp16": 1}
+
+
+class NerfHipError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib.nerf_error_string(int(code))
+        raise NerfHipError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,169 @@
+// Building blocks of the register-resident MLP chain kernels (forward and backward-data).
+// See mlp_common.hpp for the data layout.
+//
+// A workgroup is 8 waves (2 per SIMD, <= 256 VGPRs each); a wave owns 32 samples for a whole
+// pass over the network.  Weights arrive as a stream of 1 KiB A-fragment blocks through a
+// 3-slot LDS ring of 32 KiB chunks filled by LDS-DMA (global_load_lds_dwordx4): while chunk c
+// is consumed, chunks c+1 and c+2 are in flight or landed.  The only workgroup barrier is at
+// chunk entry, paired with a COUNTED vmcnt wait that leaves the newest chunk's DMA in flight.
+#pragma once
+#include "mlp_common.hpp"
+
+namespace nerf {
+namespace mlp {
+
+constexpr int RING_BYTES = RING_SLOTS * CHUNK_BYTES;            // 98304
+constexpr int BIAS_BYTES = BIAS_FLOATS * 4;                     // 12672
+constexpr int CHAIN_LDS_BYTES = RING_BYTES + BIAS_BYTES;        // 110976
+// LDS map: [bias table | ring].  The bias table comes first so that its (compile-time) offsets fit
+// the 16-bit immediate of ds_read; ring reads go through one base register plus an immediate.
+constexpr int LDS_BIAS_OFF = 0;
+constexpr int LDS_RING_OFF = BIAS_BYTES;                        // 12672, a multiple of 16
+constexpr int CHAIN_THREADS = 512;
+constexpr int DMA_PER_CHUNK = CHUNK_BYTES / (8 * 1024);        // 1 KiB pieces per wave per chunk = 4
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const char gbl_char;
+
+struct Ring {
+    const char* stream;     // start of the block stream (wave-uniform)
+    uint32_t src_off;       // byte offset of this wave's share of the next chunk to prefetch (wave-uniform)
+    uint32_t wave_off;      // wave * 4096: this wave's share inside a chunk / ring slot (wave-uniform)
+    uint32_t lane16;        // lane * 16
+    uint32_t rd_base;       // LDS address the current chunk is read from: slot*CHUNK_BYTES + lane*16
+    uint32_t stream_bytes;  // n_chunks * CHUNK_BYTES
+    int slot;               // ring slot of the current chunk
+};
+
+// Issue this wave's 4 KiB share of the chunk at stream offset `off` into ring slot `slot`.  One
+// scalar base + one per-lane 32-bit offset serve all four 1 KiB pieces: the instruction offset
+// advances the global source and the LDS destination together.
+__device__ __forceinline__ void ring_issue(const Ring& r, char* lds, uint32_t off, int slot) {
+    gbl_char* g = (gbl_char*)(r.stream + off) + r.lane16;
+    lds_char* l = (lds_char*)(lds + LDS_RING_OFF + slot * CHUNK_BYTES + r.wave_off);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+}
+
+__device__ __forceinline__ void ring_init(Ring& r, char* lds, const void* stream, int n_chunks, int lane, int wave) {
+    r.stream = (const char*)stream;
+    r.wave_off = wave * (CHUNK_BYTES / 8);
+    r.lane16 = lane * 16;
+    r.slot = RING_SLOTS - 1;          // first enter() moves to slot 0
+    r.rd_base = LDS_RING_OFF;
+    r.stream_bytes = n_chunks * CHUNK_BYTES;
+    ring_issue(r, lds, r.wave_off, 0);
+    ring_issue(r, lds, r.wave_off + CHUNK_BYTES, 1);
+    r.src_off = r.wave_off + 2 * CHUNK_BYTES;
+}
+
+// Entry into the next chunk of the stream.  On return the chunk is readable at rd_base.
+//  - vmcnt(DMA_PER_CHUNK): everything but this wave's newest chunk of DMA has landed, so its
+//    share of the chunk about to be read is in LDS;
+//  - the barrier extends that to every wave's share, and also says every wave has finished
+//    reading the previous chunk, whose slot is the one refilled next.
+__device__ __forceinline__ void ring_enter(Ring& r, char* lds) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+    __builtin_amdgcn_s_barrier();
+    r.slot = r.slot == RING_SLOTS - 1 ? 0 : r.slot + 1;
+    int refill = r.slot + 2;
+    if (refill >= RING_SLOTS) refill -= RING_SLOTS;
+    // the offset repeats with the pass; keep it opaque so that it stays one scalar register
+    // instead of a hoisted table of per-chunk addresses
+    asm volatile("" : "+s"(r.src_off));
+    ring_issue(r, lds, r.src_off, refill);
+    r.src_off += CHUNK_BYTES;
+    if (r.src_off >= r.stream_bytes) r.src_off -= r.stream_bytes;
+    r.rd_base = LDS_RING_OFF + r.slot * CHUNK_BYTES + r.lane16;
+}
+
+// accumulator tile initialised with the bias of rows 32m .. 32m+31 of `layer`
+__device__ __forceinline__ f32x16 bias_tile(const float* bias_lds, int layer, int m, int h) {
+    f32x16 acc;
+    const float* b = bias_lds + layer * BIAS_STRIDE + 32 * m + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(b + 8 * q);
+        acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+    }
+    return acc;
+}
+
+// One layer: NT output tiles, each the sum over NK0 k-steps of in0 and NK1 of in1.  B0 is the
+// layer's first block in the stream; init(m) gives the starting accumulator of tile m and
+// epi(m, acc) consumes the finished tile.  A fragments are read PF blocks ahead of their MFMA,
+// never across a chunk entry (the data is only known to have landed after its barrier).
+constexpr int PF = 3;
+// last block (layer-relative) that may have been requested once step i runs: i+PF, clipped to the
+// layer and to the chunk that block i lives in
+constexpr int pf_hi(int B0, int NB, int i) {
+    int hi = i + PF;
+    if (hi > NB - 1) hi = NB - 1;
+    const int chunk_last = ((B0 + i) / CHUNK_BLOCKS + 1) * CHUNK_BLOCKS - 1 - B0;
+    return hi < chunk_last ? hi : chunk_last;
+}
+// first block to request at step i
+constexpr int pf_lo(int B0, int NB, int i) {
+    if (i == 0 || (B0 + i) / CHUNK_BLOCKS != (B0 + i - 1) / CHUNK_BLOCKS) return i;
+    return pf_hi(B0, NB, i - 1) + 1;
+}
+
+template <int PREC, int B0, int NT, int NK0, int NK1, class Init, class Epi>
+__device__ __forceinline__ void run_layer(Ring& ring, char* lds, const typename Prec<PREC>::frag* in0,
+                                          const typename Prec<PREC>::frag* in1, Init&& init, Epi&& epi) {
+    typedef typename Prec<PREC>::frag frag;
+    constexpr int NK = NK0 + NK1, NB = NT * NK;
+    frag a[NB];
+    f32x16 acc = init(0);
+    f32x16 acc_next = acc;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int m = i / NK, ks = i % NK;
+        const int b = B0 + i;
+        if (b % CHUNK_BLOCKS == 0) ring_enter(ring, lds);
+        const int lo = pf_lo(B0, NB, i), hi = pf_hi(B0, NB, i);
+#pragma unroll
+        for (int d = 0; d <= PF; ++d) {
+            const int k2 = lo + d;
+            if (k2 <= hi)
+                a[k2] = *reinterpret_cast<const frag*>(lds + ring.rd_base + ((B0 + k2) % CHUNK_BLOCKS) * BLOCK_BYTES);
+        }
+        if (ks == 0 && m + 1 < NT) acc_next = init(m + 1);
+        acc = Prec<PREC>::mfma(a[i], ks < NK0 ? in0[ks] : in1[ks - NK0], acc);
+        if (ks == NK - 1) {
+            epi(m, acc);
+            acc = acc_next;
+        }
+    }
+}
+
+// max(x, 0) as one integer max on the float's bits (negative floats are negative integers); avoids
+// the canonicalising v_max the compiler puts in front of fmaxf on MFMA results
+__device__ __forceinline__ float relu_bits(float x) {
+    const int i = __float_as_int(x);
+    return __int_as_float(i > 0 ? i : 0);
+}
+
+// accumulator tile -> the two 16-bit fragments it becomes for the next layer
+template <int PREC, bool RELU>
+__device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename Prec<PREC>::frag& f0,
+                                              typename Prec<PREC>::frag& f1) {
+    typedef typename Prec<PREC>::elem T;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = RELU ? relu_bits(acc[j]) : acc[j];
+        const float b = RELU ? relu_bits(acc[8 + j]) : acc[8 + j];
+        f0[j] = (T)a;
+        f1[j] = (T)b;
+    }
+}
+
+// byte offset of (tensor starting at k-step ks0, wave tile wt, k-step ks) in a unit-organised buffer
+__device__ __forceinline__ size_t unit_offset(int ks0, int nks, int64_t n_wt, int64_t wt, int ks) {
+    return ((size_t)ks0 * n_wt + (size_t)wt * nks + ks) * 1024;
+}
+
+}  // namespace mlp
+}  // namespace nerf

@@ -1,0 +1,172 @@
+// Layout contract shared by the MLP kernels (pack, forward, backward chain, weight gradient).
+//
+// Network (src/nerf_project/models/nerf.py:126-209, D=8, W=256, skips=[4], use_viewdirs):
+//   L0  pts_linears.0   PE(63)            -> 256  relu
+//   L1-4 pts_linears.1-4 H(256)           -> 256  relu
+//   L5  pts_linears.5   [PE(63), H(256)]  -> 256  relu
+//   L6-7 pts_linears.6-7 H(256)           -> 256  relu
+//   L8  feature_linear + sigma_linear  H(256) -> 256 (no activation) + 1
+//   L9  rgb_layers.0    [F(256), VPE(27)] -> 128  relu
+//   L10 rgb_layers.2    G(128)            -> 3
+//
+// Orientation.  Every product is computed transposed, Y[out, sample] = W[out, in] * X[in, sample],
+// with v_mfma_f32_32x32x16_{bf16,f16}: A = a 32-row tile of W, B = 16 input features of 32
+// samples.  A wave owns 32 samples for the whole network.  The accumulator tile of one layer
+// (column = sample on the lane, rows = features in the 16 registers) is, after conversion to
+// 16 bit, directly the B operand of the next layer: register group 8s..8s+7 of output tile m is
+// the fragment of k-step 2m+s.  Activations therefore never leave the register file.
+//
+// Slots.  An activation vector is a list of k-steps of 16 "slots".  Lane half h = lane>>5,
+// fragment element j (0..7) of k-step ks is slot
+//        slot(ks, h, j) = 16*ks + 8*(j>>2) + 4*h + (j&3)
+// which for hidden activations equals the feature index (it is the C/D row map of the MFMA).
+// The positional encodings are generated straight into fragments with a slot order chosen so
+// that lane half 0 evaluates sines and lane half 1 cosines (pe_slot_feature below).
+//
+// Weight stream.  For layer L, output tile m (32 rows), k-step ks: one 1 KiB block holding
+// lane l's A fragment at byte 16*l:  element j = W[32m + (l&31)][feature of slot(ks, l>>5, j)].
+// Blocks are stored in consumption order; 32 blocks form a 32 KiB chunk, the unit of the LDS
+// ring.  The forward stream has 1184 blocks (37 chunks); the backward (transposed) stream,
+// whose A operand is a 32-row tile of W^T, has 1100 blocks padded to 1120 (35 chunks).
+#pragma once
+#include "common.hpp"
+
+namespace nerf {
+namespace mlp {
+
+constexpr int W_ = 256;          // hidden width
+constexpr int PE_FEATS = 63;     // 3 + 3*2*10
+constexpr int VPE_FEATS = 27;    // 3 + 3*2*4
+constexpr int PE_KS = 4;         // 64 slots
+constexpr int VPE_KS = 2;        // 32 slots
+constexpr int H_KS = 16;         // 256 slots
+constexpr int G_KS = 8;          // 128 slots
+constexpr int NLAYERS = 11;
+
+constexpr int TILE_SAMPLES = 256;   // samples per workgroup pass (8 waves x 32)
+constexpr int WAVE_SAMPLES = 32;
+constexpr int BLOCK_BYTES = 1024;
+constexpr int CHUNK_BLOCKS = 32;
+constexpr int CHUNK_BYTES = CHUNK_BLOCKS * BLOCK_BYTES;
+constexpr int RING_SLOTS = 3;
+
+// ---- flat parameter offsets (state_dict order) ------------------------------------------
+constexpr int OFF_W0 = 0;                       constexpr int OFF_B0 = OFF_W0 + 256 * 63;
+constexpr int OFF_W1 = OFF_B0 + 256;            constexpr int OFF_B1 = OFF_W1 + 256 * 256;
+constexpr int OFF_W2 = OFF_B1 + 256;            constexpr int OFF_B2 = OFF_W2 + 256 * 256;
+constexpr int OFF_W3 = OFF_B2 + 256;            constexpr int OFF_B3 = OFF_W3 + 256 * 256;
+constexpr int OFF_W4 = OFF_B3 + 256;            constexpr int OFF_B4 = OFF_W4 + 256 * 256;
+constexpr int OFF_W5 = OFF_B4 + 256;            constexpr int OFF_B5 = OFF_W5 + 256 * 319;
+constexpr int OFF_W6 = OFF_B5 + 256;            constexpr int OFF_B6 = OFF_W6 + 256 * 256;
+constexpr int OFF_W7 = OFF_B6 + 256;            constexpr int OFF_B7 = OFF_W7 + 256 * 256;
+constexpr int OFF_WS = OFF_B7 + 256;            constexpr int OFF_BS = OFF_WS + 256;        // sigma_linear
+constexpr int OFF_WF = OFF_BS + 1;              constexpr int OFF_BF = OFF_WF + 256 * 256;  // feature_linear
+constexpr int OFF_WR0 = OFF_BF + 256;           constexpr int OFF_BR0 = OFF_WR0 + 128 * 283;
+constexpr int OFF_WR2 = OFF_BR0 + 128;          constexpr int OFF_BR2 = OFF_WR2 + 3 * 128;
+constexpr int N_PARAMS = OFF_BR2 + 3;
+static_assert(N_PARAMS == NERF_MLP_NPARAMS, "parameter count");
+
+// ---- forward stream: blocks per layer = out_tiles * k_steps ------------------------------
+//                                   L0  L1   L2   L3   L4   L5   L6   L7   L8   L9  L10
+constexpr int FWD_TILES[NLAYERS] = {  8,  8,   8,   8,   8,   8,   8,   8,   9,   4,   1};
+constexpr int FWD_KS[NLAYERS]    = {  4, 16,  16,  16,  16,  20,  16,  16,  16,  18,   8};
+constexpr int fwd_block0(int layer) {
+    int b = 0;
+    for (int l = 0; l < layer; ++l) b += FWD_TILES[l] * FWD_KS[l];
+    return b;
+}
+constexpr int FWD_BLOCKS = fwd_block0(NLAYERS);
+static_assert(FWD_BLOCKS == 1184 && FWD_BLOCKS % CHUNK_BLOCKS == 0, "forward stream");
+constexpr int FWD_CHUNKS = FWD_BLOCKS / CHUNK_BLOCKS;   // 37
+
+// ---- backward (dgrad) stream, consumption order L10, L9, L8, L7, ..., L1 --------------------
+// index d = 0..9 for layers 10, 9, ..., 1 (L0 needs no input gradient)
+//   d0  L10: dG[128]   = W_r2^T   [128 x 16(3)]    4 tiles x 1 ks
+//   d1  L9 : dF[256]   = W_r0^T   [256 x 128]      8 tiles x 8 ks   (view-direction rows not needed)
+//   d2  L8 : dH7[256]  = [W_f; w_sigma]^T [256 x 272] 8 tiles x 17 ks
+//   d3.. L7, L6, L5 (H rows only), L4, L3, L2, L1: 8 tiles x 16 ks
+constexpr int NBWD = 10;
+constexpr int BWD_TILES[NBWD] = {4, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+constexpr int BWD_KS[NBWD]    = {1, 8, 17, 16, 16, 16, 16, 16, 16, 16};
+constexpr int bwd_block0(int d) {
+    int b = 0;
+    for (int i = 0; i < d; ++i) b += BWD_TILES[i] * BWD_KS[i];
+    return b;
+}
+constexpr int BWD_BLOCKS_REAL = bwd_block0(NBWD);        // 1100
+constexpr int BWD_CHUNKS = (BWD_BLOCKS_REAL + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;   // 35
+constexpr int BWD_BLOCKS = BWD_CHUNKS * CHUNK_BLOCKS;   // 1120 (tail blocks are zero, never read)
+static_assert(BWD_BLOCKS_REAL == 1100, "backward stream");
+
+// ---- bias table (fp32), one padded row per forward layer ------------------------------------
+constexpr int BIAS_STRIDE = 288;                         // L8 has 257 real rows
+constexpr int BIAS_FLOATS = NLAYERS * BIAS_STRIDE;       // 3168 floats = 12672 B
+
+// ---- packed buffer layout ----------------------------------------------------------------------
+constexpr int64_t PACK_FWD_OFF = 0;
+constexpr int64_t PACK_BWD_OFF = PACK_FWD_OFF + (int64_t)FWD_BLOCKS * BLOCK_BYTES;
+constexpr int64_t PACK_BIAS_OFF = PACK_BWD_OFF + (int64_t)BWD_BLOCKS * BLOCK_BYTES;
+constexpr int64_t PACK_BYTES = PACK_BIAS_OFF + (int64_t)BIAS_FLOATS * 4;
+
+// ---- slot maps --------------------------------------------------------------------------------
+__host__ __device__ constexpr int slot_of(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// Positional-encoding fragment generation order.  "combo" q = 8*ks + j enumerates the
+// (frequency l, component c) pairs: q = 3*l + c for q < 3*L; lane half 0 holds sin(2^l x_c),
+// lane half 1 cos(2^l x_c).  Two more combos carry the raw coordinates: q = 3L -> (x, y),
+// q = 3L+1 -> (z, pad).  Returns the reference feature index of (combo, half) or -1 for padding.
+// Reference order (models/nerf.py:68-76): [x(3), sin f0 (3), cos f0 (3), sin f1 (3), ...].
+__host__ __device__ constexpr int pe_combo_feature(int q, int h, int L) {
+    if (q < 3 * L) {
+        const int l = q / 3, c = q % 3;
+        return 3 + 6 * l + 3 * h + c;
+    }
+    if (q == 3 * L) return h;            // x, y
+    if (q == 3 * L + 1) return h == 0 ? 2 : -1;   // z, pad
+    return -1;
+}
+// slot index -> reference feature (or -1) for the PE (L=10, 64 slots) and VPE (L=4, 32 slots) inputs
+__host__ __device__ constexpr int pe_slot_feature(int slot, int L) {
+    const int ks = slot >> 4, r = slot & 15;
+    const int h = (r >> 2) & 1;
+    const int j = (r & 3) | ((r >> 3) << 2);
+    return pe_combo_feature(8 * ks + j, h, L);
+}
+
+// ---- saved-activation / gradient unit layout -----------------------------------------------------
+// A "unit" is one k-step (16 slots) of one 32-sample wave tile: a 1 KiB block
+// [32 samples][16 positions] of 16-bit values, position p = 8*h + j <-> slot(ks, h, j), i.e. lane
+// l = sample + 32*h stores its 16-byte fragment at byte 32*sample + 16*h.
+// Tensors are stored tensor-major: tensor t starts at unit  SAVED_KS0[t] * n_wave_tiles.
+//   saved: PE(4) H0..H7(16 each) F(16) VPE(2) G(8)
+enum { SV_PE = 0, SV_H0 = 1, SV_F = 9, SV_VPE = 10, SV_G = 11, SV_NT = 12 };
+constexpr int SAVED_KS[SV_NT] = {4, 16, 16, 16, 16, 16, 16, 16, 16, 16, 2, 8};
+constexpr int saved_ks0(int t) { int k = 0; for (int i = 0; i < t; ++i) k += SAVED_KS[i]; return k; }
+constexpr int SAVED_UNITS = saved_ks0(SV_NT);   // 158 KiB per 32 samples
+//   gradients dZ of each layer's pre-activation: L0..L7 (16 each), L8 (17: 256 feature + sigma), L9 (8), L10 (1)
+constexpr int DZ_KS[NLAYERS] = {16, 16, 16, 16, 16, 16, 16, 16, 17, 8, 1};
+constexpr int dz_ks0(int l) { int k = 0; for (int i = 0; i < l; ++i) k += DZ_KS[i]; return k; }
+constexpr int DZ_UNITS = dz_ks0(NLAYERS);       // 154 KiB per 32 samples
+
+// ---- operand types -------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int PREC> struct Prec;
+template <> struct Prec<NERF_PREC_BF16> {
+    typedef __bf16 elem;
+    typedef __bf16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Prec<NERF_PREC_FP16> {
+    typedef _Float16 elem;
+    typedef _Float16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+}  // namespace mlp
+}  // namespace nerf

@@ -1,0 +1,257 @@
+// Fused positional encoding + 8x256 MLP forward (src/nerf_project/models/nerf.py:68-76, :173-209
+// and the point / view-direction set-up of render_rays, :409-421) on bf16/fp16 MFMA.
+//
+// MFMA-bound: 1184 v_mfma_f32_32x32x16 per 32 samples (600 064 padded MAC/sample against
+// 593 408 algorithmic).  HBM traffic is 4 B (z) in and 16 B (raw) out per sample, plus the
+// optional saved activations for training.  Layout and schedule: mlp_common.hpp, mlp_chain.hpp.
+#include <type_traits>
+#include "mlp_chain.hpp"
+
+namespace nerf {
+namespace mlp {
+
+struct FwdArgs {
+    int64_t M;            // samples
+    int64_t n_tiles;      // ceil(M / 256)
+    int S;                // samples per ray (fused input mode)
+    const float* rays_o;  // [n_rays,3]
+    const float* rays_d;  // [n_rays,3]
+    const float* z;       // [M]
+    const float* x_pts;   // [M,63]  (encoded input mode)
+    const float* x_views; // [M,27]
+    const char* packed;
+    float* raw;           // [M,4]
+    char* saved;          // nullable
+};
+
+// sin(2 pi r) on the hardware unit (input in revolutions)
+__device__ __forceinline__ float sin_rev(float r) { return __builtin_amdgcn_sinf(r); }
+
+// Fragments of the positional encoding of (px,py,pz) with L frequencies 2^l (no pi), NKS k-steps.
+// Lane half h = 0 evaluates sines, h = 1 cosines (a quarter-revolution phase).  The argument is
+// reduced exactly: t = p/(2 pi) as a two-term product, 2^l * t_hi is exact, fract() is exact.
+template <int PREC, int L, int NKS>
+__device__ __forceinline__ void encode(float px, float py, float pz, int h, typename Prec<PREC>::frag* out) {
+    typedef typename Prec<PREC>::elem T;
+    constexpr float C_HI = 0.15915494f;                 // fl32(1 / (2 pi))
+    constexpr float C_LO = 6.4206382e-09f; // 1/(2 pi) - C_HI
+    const float p[3] = {px, py, pz};
+    float thi[3], tlo[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        thi[c] = p[c] * C_HI;
+        tlo[c] = fmaf(p[c], C_HI, -thi[c]) + p[c] * C_LO;
+    }
+    const float phase = h ? 0.25f : 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = 8 * ks + j;
+            float v;
+            if (q < 3 * L) {
+                const int l = q / 3, c = q % 3;
+                const float sc = (float)(1 << l);
+                const float r = __builtin_amdgcn_fractf(thi[c] * sc) + fmaf(tlo[c], sc, phase);
+                v = sin_rev(r);
+            } else if (q == 3 * L) {
+                v = h ? py : px;
+            } else if (q == 3 * L + 1) {
+                v = h ? 0.0f : pz;
+            } else {
+                v = 0.0f;
+            }
+            out[ks][j] = (T)v;
+        }
+    }
+}
+
+// fragments from pre-encoded rows x[m, 0..NF)
+template <int PREC, int L, int NKS, int NF>
+__device__ __forceinline__ void gather_encoded(const float* __restrict__ x, int64_t m, bool valid, int h,
+                                               typename Prec<PREC>::frag* out) {
+    typedef typename Prec<PREC>::elem T;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f0 = pe_combo_feature(8 * ks + j, 0, L), f1 = pe_combo_feature(8 * ks + j, 1, L);
+            const int f = h ? f1 : f0;
+            const float v = (valid && f >= 0) ? x[m * NF + f] : 0.0f;
+            out[ks][j] = (T)v;
+        }
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
+                                          int lane_off, const typename Prec<PREC>::frag& f) {
+    *reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
+}
+
+template <int PREC, bool SAVE, bool ENCODED>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs a) {
+    typedef typename Prec<PREC>::frag frag;
+    __shared__ __attribute__((aligned(16))) char lds[CHAIN_LDS_BYTES];
+    float* bias_lds = reinterpret_cast<float*>(lds + LDS_BIAS_OFF);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int lane_off = c * 32 + h * 16;        // byte offset of this lane's fragment in a saved unit
+
+    {   // bias table -> LDS (plain loads, before any LDS-DMA is in flight)
+        const float* bg = reinterpret_cast<const float*>(a.packed + PACK_BIAS_OFF);
+        for (int i = threadIdx.x; i < BIAS_FLOATS; i += CHAIN_THREADS) bias_lds[i] = bg[i];
+    }
+    __syncthreads();
+
+    Ring ring;
+    ring_init(ring, lds, a.packed + PACK_FWD_OFF, FWD_CHUNKS, lane, wave);
+    const int64_t n_wt = a.n_tiles * 8;
+
+    for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t wt = tile * 8 + wave;
+        const int64_t m = wt * WAVE_SAMPLES + c;
+        const bool valid = m < a.M;
+
+        frag pe[PE_KS];
+        float vx = 0.f, vy = 0.f, vz = 0.f;   // unit view direction (fused mode)
+        if (ENCODED) {
+            gather_encoded<PREC, 10, PE_KS, PE_FEATS>(a.x_pts, m, valid, h, pe);
+        } else {
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (valid) {
+                const int64_t ray = m / a.S;
+                const float zz = a.z[m];
+                const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+                const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+                px = __fadd_rn(ox, __fmul_rn(dx, zz));        // nerf.py:409
+                py = __fadd_rn(oy, __fmul_rn(dy, zz));
+                pz = __fadd_rn(oz, __fmul_rn(dz, zz));
+                const float n = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+                vx = dx / n; vy = dy / n; vz = dz / n;        // nerf.py:417
+            }
+            encode<PREC, 10, PE_KS>(px, py, pz, h, pe);
+        }
+        if (SAVE) {
+#pragma unroll
+            for (int ks = 0; ks < PE_KS; ++ks)
+                save_frag<PREC>(a.saved, saved_ks0(SV_PE), PE_KS, n_wt, wt, ks, lane_off, pe[ks]);
+        }
+
+        frag ha[H_KS], hb[H_KS];
+        auto hidden = [&](auto LAYER, frag* out) {
+            return [&, out](int mt, const f32x16& acc) {
+                constexpr int layer = decltype(LAYER)::value;
+                tile_to_frags<PREC, true>(acc, out[2 * mt], out[2 * mt + 1]);
+                if (SAVE) {
+                    save_frag<PREC>(a.saved, saved_ks0(SV_H0 + layer), H_KS, n_wt, wt, 2 * mt, lane_off, out[2 * mt]);
+                    save_frag<PREC>(a.saved, saved_ks0(SV_H0 + layer), H_KS, n_wt, wt, 2 * mt + 1, lane_off,
+                                    out[2 * mt + 1]);
+                }
+            };
+        };
+#define NERF_BIAS(LAYER) [&](int mt) { return bias_tile(bias_lds, LAYER, mt, h); }
+#define NERF_IC(N) std::integral_constant<int, N>()
+        run_layer<PREC, fwd_block0(0), 8, PE_KS, 0>(ring, lds, pe, pe, NERF_BIAS(0), hidden(NERF_IC(0), ha));
+        run_layer<PREC, fwd_block0(1), 8, H_KS, 0>(ring, lds, ha, ha, NERF_BIAS(1), hidden(NERF_IC(1), hb));
+        run_layer<PREC, fwd_block0(2), 8, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(2), hidden(NERF_IC(2), ha));
+        run_layer<PREC, fwd_block0(3), 8, H_KS, 0>(ring, lds, ha, ha, NERF_BIAS(3), hidden(NERF_IC(3), hb));
+        run_layer<PREC, fwd_block0(4), 8, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(4), hidden(NERF_IC(4), ha));
+        run_layer<PREC, fwd_block0(5), 8, PE_KS, H_KS>(ring, lds, pe, ha, NERF_BIAS(5), hidden(NERF_IC(5), hb));
+        run_layer<PREC, fwd_block0(6), 8, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(6), hidden(NERF_IC(6), ha));
+        run_layer<PREC, fwd_block0(7), 8, H_KS, 0>(ring, lds, ha, ha, NERF_BIAS(7), hidden(NERF_IC(7), hb));
+
+        // L8: feature_linear (no activation) -> ha, sigma_linear -> row 0 of tile 8
+        float sigma = 0.f;
+        run_layer<PREC, fwd_block0(8), 9, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(8), [&](int mt, const f32x16& acc) {
+            if (mt < 8) {
+                tile_to_frags<PREC, false>(acc, ha[2 * mt], ha[2 * mt + 1]);
+                if (SAVE) {
+                    save_frag<PREC>(a.saved, saved_ks0(SV_F), H_KS, n_wt, wt, 2 * mt, lane_off, ha[2 * mt]);
+                    save_frag<PREC>(a.saved, saved_ks0(SV_F), H_KS, n_wt, wt, 2 * mt + 1, lane_off, ha[2 * mt + 1]);
+                }
+            } else {
+                sigma = acc[0];
+            }
+        });
+
+        // L9: rgb_layers.0 on [feature, view encoding] -> relu -> G (first 8 k-steps of hb)
+        frag vpe[VPE_KS];
+        if (ENCODED) gather_encoded<PREC, 4, VPE_KS, VPE_FEATS>(a.x_views, m, valid, h, vpe);
+        else encode<PREC, 4, VPE_KS>(vx, vy, vz, h, vpe);
+        if (SAVE) {
+#pragma unroll
+            for (int ks = 0; ks < VPE_KS; ++ks)
+                save_frag<PREC>(a.saved, saved_ks0(SV_VPE), VPE_KS, n_wt, wt, ks, lane_off, vpe[ks]);
+        }
+        run_layer<PREC, fwd_block0(9), 4, H_KS, VPE_KS>(ring, lds, ha, vpe, NERF_BIAS(9), [&](int mt, const f32x16& acc) {
+            tile_to_frags<PREC, true>(acc, hb[2 * mt], hb[2 * mt + 1]);
+            if (SAVE) {
+                save_frag<PREC>(a.saved, saved_ks0(SV_G), G_KS, n_wt, wt, 2 * mt, lane_off, hb[2 * mt]);
+                save_frag<PREC>(a.saved, saved_ks0(SV_G), G_KS, n_wt, wt, 2 * mt + 1, lane_off, hb[2 * mt + 1]);
+            }
+        });
+
+        // L10: rgb_layers.2 -> rows 0..2; output (rgb_raw, sigma_raw) per sample from lane half 0
+        run_layer<PREC, fwd_block0(10), 1, G_KS, 0>(ring, lds, hb, hb, NERF_BIAS(10), [&](int, const f32x16& acc) {
+            if (valid && h == 0)
+                reinterpret_cast<float4*>(a.raw)[m] = make_float4(acc[0], acc[1], acc[2], sigma);
+        });
+#undef NERF_BIAS
+#undef NERF_IC
+    }
+    // LDS-DMA prefetched for a pass that does not exist must land before the wave ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace mlp
+}  // namespace nerf
+
+using namespace nerf::mlp;
+
+extern "C" int64_t nerf_mlp_saved_bytes(int64_t n_samples) {
+    const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    return n_tiles * 8 * (int64_t)SAVED_UNITS * 1024;
+}
+
+static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* stream) {
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    if (a.M == 0) return NERF_OK;
+    int64_t grid = a.n_tiles < 256 ? a.n_tiles : 256;   // one persistent workgroup per CU
+    const dim3 g((unsigned)grid), b(CHAIN_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    const bool save = a.saved != nullptr;
+#define NERF_LAUNCH(P, SV, EN) hipLaunchKernelGGL((mlp_fwd_kernel<P, SV, EN>), g, b, 0, st, a)
+#define NERF_PICK(P)                                            \
+    if (save) { if (encoded) NERF_LAUNCH(P, true, true); else NERF_LAUNCH(P, true, false); } \
+    else { if (encoded) NERF_LAUNCH(P, false, true); else NERF_LAUNCH(P, false, false); }
+    if (precision == NERF_PREC_BF16) { NERF_PICK(NERF_PREC_BF16) } else { NERF_PICK(NERF_PREC_FP16) }
+#undef NERF_PICK
+#undef NERF_LAUNCH
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_fwd(int64_t n_rays, int S, const float* rays_o, const float* rays_d, const float* z,
+                            const void* packed, int precision, float* raw, void* saved, void* stream) {
+    NERF_REQUIRE(rays_o && rays_d && z && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(n_rays >= 0 && S >= 1, NERF_E_SHAPE);
+    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256), NERF_E_ALIGN);
+    FwdArgs a{};
+    a.M = n_rays * S; a.n_tiles = (a.M + TILE_SAMPLES - 1) / TILE_SAMPLES; a.S = S;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.packed = (const char*)packed; a.raw = raw;
+    a.saved = (char*)saved;
+    return launch_fwd(a, precision, false, stream);
+}
+
+extern "C" int nerf_mlp_fwd_encoded(int64_t M, const float* x_pts, const float* x_views, const void* packed,
+                                    int precision, float* raw, void* saved, void* stream) {
+    NERF_REQUIRE(x_pts && x_views && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
+    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256), NERF_E_ALIGN);
+    FwdArgs a{};
+    a.M = M; a.n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES; a.S = 1;
+    a.x_pts = x_pts; a.x_views = x_views; a.packed = (const char*)packed; a.raw = raw; a.saved = (char*)saved;
+    return launch_fwd(a, precision, true, stream);
+}

@@ -1,0 +1,122 @@
+// Weight packing: flat fp32 parameters (state_dict order) -> the MFMA fragment streams and bias
+// table described in mlp_common.hpp.  Runs once per weight update (about 3.5 MB of traffic).
+#include "mlp_common.hpp"
+
+namespace nerf {
+namespace mlp {
+
+__device__ __forceinline__ float fwd_weight(const float* __restrict__ P, int L, int row, int ks, int slot) {
+    switch (L) {
+        case 0: {
+            const int f = pe_slot_feature(slot, 10);
+            return f >= 0 ? P[OFF_W0 + row * 63 + f] : 0.0f;
+        }
+        case 1: return P[OFF_W1 + row * 256 + slot];
+        case 2: return P[OFF_W2 + row * 256 + slot];
+        case 3: return P[OFF_W3 + row * 256 + slot];
+        case 4: return P[OFF_W4 + row * 256 + slot];
+        case 5: {
+            if (ks < PE_KS) {
+                const int f = pe_slot_feature(slot, 10);
+                return f >= 0 ? P[OFF_W5 + row * 319 + f] : 0.0f;
+            }
+            return P[OFF_W5 + row * 319 + 63 + (slot - 64)];
+        }
+        case 6: return P[OFF_W6 + row * 256 + slot];
+        case 7: return P[OFF_W7 + row * 256 + slot];
+        case 8:
+            if (row < 256) return P[OFF_WF + row * 256 + slot];
+            return row == 256 ? P[OFF_WS + slot] : 0.0f;
+        case 9: {
+            if (row >= 128) return 0.0f;
+            if (ks < H_KS) return P[OFF_WR0 + row * 283 + slot];
+            const int f = pe_slot_feature(slot - 256, 4);
+            return f >= 0 ? P[OFF_WR0 + row * 283 + 256 + f] : 0.0f;
+        }
+        default: return row < 3 ? P[OFF_WR2 + row * 128 + slot] : 0.0f;
+    }
+}
+
+// A = W^T: row = input feature, k = output slot
+__device__ __forceinline__ float bwd_weight(const float* __restrict__ P, int d, int rin, int k) {
+    switch (d) {
+        case 0: return (rin < 128 && k < 3) ? P[OFF_WR2 + k * 128 + rin] : 0.0f;
+        case 1: return k < 128 ? P[OFF_WR0 + k * 283 + rin] : 0.0f;
+        case 2:
+            if (k < 256) return P[OFF_WF + k * 256 + rin];
+            return k == 256 ? P[OFF_WS + rin] : 0.0f;
+        case 3: return P[OFF_W7 + k * 256 + rin];
+        case 4: return P[OFF_W6 + k * 256 + rin];
+        case 5: return P[OFF_W5 + k * 319 + 63 + rin];
+        case 6: return P[OFF_W4 + k * 256 + rin];
+        case 7: return P[OFF_W3 + k * 256 + rin];
+        case 8: return P[OFF_W2 + k * 256 + rin];
+        default: return P[OFF_W1 + k * 256 + rin];
+    }
+}
+
+__device__ __forceinline__ float bias_value(const float* __restrict__ P, int L, int row) {
+    if (L < 8) {
+        const int off[8] = {OFF_B0, OFF_B1, OFF_B2, OFF_B3, OFF_B4, OFF_B5, OFF_B6, OFF_B7};
+        return row < 256 ? P[off[L] + row] : 0.0f;
+    }
+    if (L == 8) return row < 256 ? P[OFF_BF + row] : (row == 256 ? P[OFF_BS] : 0.0f);
+    if (L == 9) return row < 128 ? P[OFF_BR0 + row] : 0.0f;
+    return row < 3 ? P[OFF_BR2 + row] : 0.0f;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, char* __restrict__ out) {
+    typedef typename Prec<PREC>::elem T;
+    T* fwd = reinterpret_cast<T*>(out + PACK_FWD_OFF);
+    T* bwd = reinterpret_cast<T*>(out + PACK_BWD_OFF);
+    float* bias = reinterpret_cast<float*>(out + PACK_BIAS_OFF);
+    constexpr int64_t NF = (int64_t)FWD_BLOCKS * 512, NB = (int64_t)BWD_BLOCKS * 512;
+    const int64_t total = NF + NB + BIAS_FLOATS;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < NF) {
+            int b = (int)(e >> 9);
+            const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
+            int L = 0;
+            while (L + 1 < NLAYERS && b >= FWD_TILES[L] * FWD_KS[L]) { b -= FWD_TILES[L] * FWD_KS[L]; ++L; }
+            const int m = b / FWD_KS[L], ks = b - m * FWD_KS[L];
+            const float v = fwd_weight(P, L, 32 * m + (lane & 31), ks, slot_of(ks, lane >> 5, j));
+            fwd[e] = (T)v;
+        } else if (e < NF + NB) {
+            const int64_t eb = e - NF;
+            int b = (int)(eb >> 9);
+            const int lane = (int)(eb >> 3) & 63, j = (int)eb & 7;
+            float v = 0.0f;
+            if (b < BWD_BLOCKS_REAL) {
+                int d = 0;
+                while (d + 1 < NBWD && b >= BWD_TILES[d] * BWD_KS[d]) { b -= BWD_TILES[d] * BWD_KS[d]; ++d; }
+                const int m = b / BWD_KS[d], ks = b - m * BWD_KS[d];
+                v = bwd_weight(P, d, 32 * m + (lane & 31), slot_of(ks, lane >> 5, j));
+            }
+            bwd[eb] = (T)v;
+        } else {
+            const int i = (int)(e - NF - NB);
+            bias[i] = bias_value(P, i / BIAS_STRIDE, i % BIAS_STRIDE);
+        }
+    }
+}
+
+}  // namespace mlp
+}  // namespace nerf
+
+extern "C" int64_t nerf_mlp_packed_bytes(void) { return nerf::mlp::PACK_BYTES; }
+
+extern "C" int nerf_mlp_pack(const float* params, int precision, void* packed, void* stream) {
+    NERF_REQUIRE(params && packed, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(packed, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    const dim3 grid(1024), block(256);
+    if (precision == NERF_PREC_BF16)
+        hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_BF16>, grid, block, 0, (hipStream_t)stream, params,
+                           (char*)packed);
+    else
+        hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_FP16>, grid, block, 0, (hipStream_t)stream, params,
+                           (char*)packed);
+    return nerf_launch_status();
+}

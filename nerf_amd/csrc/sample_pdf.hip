@@ -1,0 +1,249 @@
+// Hierarchical sampling (src/nerf_project/models/nerf.py:237-313), the per-ray sort of
+// scripts/train_nerf.py:320, and the two fused as the coarse->fine glue of
+// scripts/train_nerf.py:309-320.
+//
+// One wavefront owns one ray.  The CDF is built once per ray by a wave-level fp64 prefix sum
+// (rounded to fp32 per knot, as the reference's CPU cumsum does) and parked in LDS together
+// with the bin edges; every lane then inverts the CDF for its own uniforms with a binary
+// search over the LDS copy.  The sort is a bitonic network held in registers, E elements per
+// lane, with cross-lane exchanges on wave shuffles.
+// Compiled with -ffp-contract=off (the interpolation is unfused fp32 in the reference).
+#include <math.h>
+#include "common.hpp"
+
+namespace nerf {
+
+// ---- CDF build -------------------------------------------------------------
+// weight(i) for i in [0, n_w) -> cdf[0..n_w] in LDS.  All 64 lanes must call.
+template <class WeightFn>
+__device__ __forceinline__ void build_cdf(WeightFn weight, int n_w, float* __restrict__ cdf, int lane) {
+    double tot = 0.0;
+    for (int i = lane; i < n_w; i += 64) tot += (double)(weight(i) + 1e-5f);   // nerf.py:237
+    const float total = (float)wave_sum(tot);                                   // nerf.py:240 (fp32 result)
+    double carry = 0.0;
+    if (lane == 0) cdf[0] = 0.0f;                                               // nerf.py:246
+    for (int i0 = 0; i0 < n_w; i0 += 64) {
+        const int i = i0 + lane;
+        const float pdf = i < n_w ? __fdiv_rn(weight(i) + 1e-5f, total) : 0.0f;
+        const double incl = wave_incl_sum((double)pdf, lane);
+        if (i < n_w) cdf[i + 1] = (float)(carry + incl);                        // nerf.py:243
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+// ---- inverse CDF -------------------------------------------------------------
+// nerf.py:262-313 for one uniform; returns the sample, *ind = searchsorted(cdf, u, right=True)
+__device__ __forceinline__ float invert_cdf(float u, const float* __restrict__ cdf,
+                                            const float* __restrict__ bins, int n_bins, int* ind) {
+    int lo = 0, hi = n_bins;  // first index with cdf[idx] > u
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    *ind = lo;
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < n_bins - 1 ? lo : n_bins - 1;
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = bins[below], b1 = bins[above];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;
+    const float t = __fdiv_rn(u - c0, denom);
+    return b0 + t * (b1 - b0);
+}
+
+// ---- bitonic sort, E elements per lane, element index = lane*E + r ------------
+template <int E>
+__device__ __forceinline__ void bitonic_sort(float (&v)[E], int lane) {
+    constexpr int P = 64 * E;
+#pragma unroll
+    for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & j) == 0) {
+                        const bool asc = (((lane * E + r) & k) == 0);
+                        const float a = v[r], b = v[r | j];
+                        const float mn = fminf(a, b), mx = fmaxf(a, b);
+                        v[r] = asc ? mn : mx;
+                        v[r | j] = asc ? mx : mn;
+                    }
+                }
+            } else {
+                const int lj = j / E;
+                const bool lower = (lane & lj) == 0;
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const float o = __shfl_xor(v[r], lj, 64);
+                    const bool asc = (((lane * E + r) & k) == 0);
+                    v[r] = (lower == asc) ? fminf(v[r], o) : fmaxf(v[r], o);
+                }
+            }
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void store_sorted(const float (&v)[E], float* __restrict__ out, int n, int lane) {
+    if (E == 4 && (n & 3) == 0 && (((uintptr_t)out) & 15) == 0) {
+        if (lane * 4 < n) reinterpret_cast<float4*>(out)[lane] = make_float4(v[0], v[1], v[2], v[3]);
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < E; ++r)
+        if (lane * E + r < n) out[lane * E + r] = v[r];
+}
+
+// ---- kernels -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_pdf_kernel(int64_t n_rays, int n_bins, const float* __restrict__ bins,
+                                                         int64_t bins_ld, const float* __restrict__ weights,
+                                                         int64_t w_ld, int n_samples, const float* __restrict__ u,
+                                                         float* __restrict__ samples, int32_t* __restrict__ inds,
+                                                         int lds_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* cdf = smem + (size_t)wv * 2 * lds_stride;
+    float* lb = cdf + lds_stride;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    if (ray >= n_rays) return;   // whole wave exits; no block-level barrier below
+    const float* w = weights + ray * w_ld;
+    const float* b = bins + ray * bins_ld;
+    build_cdf([&](int i) { return w[i]; }, n_bins - 1, cdf, lane);
+    for (int i = lane; i < n_bins; i += 64) lb[i] = b[i];
+    wave_lds_sync();
+    for (int j = lane; j < n_samples; j += 64) {
+        const float uj = u ? u[ray * n_samples + j] : linspace01(j, n_samples);   // nerf.py:251-255
+        int ind;
+        const float s = invert_cdf(uj, cdf, lb, n_bins, &ind);
+        samples[ray * n_samples + j] = s;
+        if (inds) inds[ray * n_samples + j] = ind;
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void sort_rows_kernel(int64_t n_rows, int n_a, const float* __restrict__ a,
+                                                        int n_b, const float* __restrict__ b,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int n = n_a + n_b;
+    float v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {   // any initial placement sorts; this one loads coalesced
+        const int i = r * 64 + lane;
+        v[r] = i < n_a ? a[row * n_a + i] : (i < n ? b[row * n_b + (i - n_a)] : INFINITY);
+    }
+    bitonic_sort<E>(v, lane);
+    store_sorted<E>(v, out + row * n, n, lane);
+}
+
+// coarse->fine glue: sample_pdf on (midpoints, w[1:-1]+1e-5) then sort(cat(z_coarse, z_fine))
+template <int E>
+__global__ __launch_bounds__(256) void sample_merge_kernel(int64_t n_rays, int Sc, const float* __restrict__ zc,
+                                                           const float* __restrict__ wc, int n_fine,
+                                                           const float* __restrict__ u, float* __restrict__ zout,
+                                                           float* __restrict__ zfine, int lds_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* cdf = smem + (size_t)wv * 2 * lds_stride;
+    float* lb = cdf + lds_stride;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    if (ray >= n_rays) return;
+    const float* z = zc + ray * Sc;
+    const float* w = wc + ray * Sc;
+    const int n_bins = Sc - 1;
+    // weights_pdf = weights_coarse[..., 1:-1] + 1e-5  (train_nerf.py:312)
+    build_cdf([&](int i) { return w[i + 1] + 1e-5f; }, n_bins - 1, cdf, lane);
+    for (int i = lane; i < n_bins; i += 64) lb[i] = 0.5f * (z[i + 1] + z[i]);   // train_nerf.py:309
+    wave_lds_sync();
+    const int n = Sc + n_fine;
+    float v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = r * 64 + lane;
+        float x = INFINITY;
+        if (i < n_fine) {
+            const float uj = u ? u[ray * n_fine + i] : linspace01(i, n_fine);
+            int ind;
+            x = invert_cdf(uj, cdf, lb, n_bins, &ind);
+            if (zfine) zfine[ray * n_fine + i] = x;
+        } else if (i < n) {
+            x = z[i - n_fine];
+        }
+        v[r] = x;
+    }
+    bitonic_sort<E>(v, lane);
+    store_sorted<E>(v, zout + ray * n, n, lane);
+}
+
+static inline int elems_per_lane(int n) {
+    int e = 1;
+    while (64 * e < n) e <<= 1;
+    return e;
+}
+
+}  // namespace nerf
+
+extern "C" int nerf_sample_pdf(int64_t n_rays, int n_bins, const float* bins, int64_t bins_ld,
+                               const float* weights, int64_t w_ld, int n_samples, const float* u,
+                               float* samples, int32_t* inds, void* stream) {
+    NERF_REQUIRE(bins && weights && samples, NERF_E_NULL);
+    NERF_REQUIRE(n_rays >= 0 && n_bins >= 2 && n_bins <= 1024 && n_samples >= 1, NERF_E_SHAPE);
+    NERF_REQUIRE(bins_ld >= n_bins && w_ld >= n_bins - 1, NERF_E_SHAPE);
+    if (n_rays == 0) return NERF_OK;
+    const int lds_stride = (n_bins + 3) & ~3;
+    const size_t lds = (size_t)4 * 2 * lds_stride * sizeof(float);
+    const int64_t blocks = (n_rays + 3) / 4;
+    NERF_REQUIRE(blocks <= 0x7fffffff, NERF_E_SHAPE);
+    hipLaunchKernelGGL(nerf::sample_pdf_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
+                       n_rays, n_bins, bins, bins_ld, weights, w_ld, n_samples, u, samples, inds, lds_stride);
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_sort_rows(int64_t n_rows, int n_a, const float* a, int n_b, const float* b, float* out,
+                              void* stream) {
+    NERF_REQUIRE(a && out && (b || n_b == 0), NERF_E_NULL);
+    NERF_REQUIRE(n_rows >= 0 && n_a >= 1 && n_b >= 0 && n_a + n_b <= 1024, NERF_E_SHAPE);
+    if (n_rows == 0) return NERF_OK;
+    const int64_t blocks = (n_rows + 3) / 4;
+    NERF_REQUIRE(blocks <= 0x7fffffff, NERF_E_SHAPE);
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define NERF_SORT(E) hipLaunchKernelGGL(nerf::sort_rows_kernel<E>, grid, block, 0, st, n_rows, n_a, a, n_b, b, out)
+    switch (nerf::elems_per_lane(n_a + n_b)) {
+        case 1: NERF_SORT(1); break;
+        case 2: NERF_SORT(2); break;
+        case 4: NERF_SORT(4); break;
+        case 8: NERF_SORT(8); break;
+        default: NERF_SORT(16); break;
+    }
+#undef NERF_SORT
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_sample_merge(int64_t n_rays, int Sc, const float* z_coarse, const float* w_coarse,
+                                 int n_fine, const float* u, float* z_out, float* z_fine_out, void* stream) {
+    NERF_REQUIRE(z_coarse && w_coarse && z_out, NERF_E_NULL);
+    NERF_REQUIRE(n_rays >= 0 && Sc >= 3 && Sc <= 1024 && n_fine >= 1 && Sc + n_fine <= 1024, NERF_E_SHAPE);
+    if (n_rays == 0) return NERF_OK;
+    const int lds_stride = (Sc + 3) & ~3;
+    const size_t lds = (size_t)4 * 2 * lds_stride * sizeof(float);
+    const int64_t blocks = (n_rays + 3) / 4;
+    NERF_REQUIRE(blocks <= 0x7fffffff, NERF_E_SHAPE);
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define NERF_SM(E)                                                                                        \
+    hipLaunchKernelGGL(nerf::sample_merge_kernel<E>, grid, block, lds, st, n_rays, Sc, z_coarse, w_coarse, \
+                       n_fine, u, z_out, z_fine_out, lds_stride)
+    switch (nerf::elems_per_lane(Sc + n_fine)) {
+        case 1: NERF_SM(1); break;
+        case 2: NERF_SM(2); break;
+        case 4: NERF_SM(4); break;
+        case 8: NERF_SM(8); break;
+        default: NERF_SM(16); break;
+    }
+#undef NERF_SM
+    return nerf_launch_status();
+}

@@ -1,0 +1,336 @@
+"""Python-side launchers for the HIP kernels: tensor validation, output allocation,
+and the torch.autograd.Function wrappers.  Every function here requires GPU
+(ROCm "cuda") fp32 tensors and enqueues on torch's current stream; nothing
+falls back to PyTorch arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _C
+from ._C import check, lib
+
+
+# ---------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------
+
+def _gpu_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got device {t.device}); nerf_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+# ---------------------------------------------------------------------------
+# rays / sample placement / positional encoding
+# ---------------------------------------------------------------------------
+
+def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor, row0: int = 0,
+             nrows: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rows [row0, row0+nrows) of the pinhole frame; (rays_o, rays_d) of shape [nrows, W, 3]."""
+    c2w = _gpu_f32(c2w, "c2w")
+    if c2w.dim() != 2 or c2w.shape[1] != 4 or c2w.shape[0] not in (3, 4):
+        raise ValueError(f"c2w must be [4,4] or [3,4], got {tuple(c2w.shape)}")
+    H, W = int(H), int(W)
+    nrows = H - row0 if nrows is None else int(nrows)
+    ro = torch.empty((nrows, W, 3), dtype=torch.float32, device=c2w.device)
+    rd = torch.empty((nrows, W, 3), dtype=torch.float32, device=c2w.device)
+    with torch.cuda.device(c2w.device):
+        check(lib.nerf_get_rays(H, W, float(focal), _p(c2w), 4, int(row0), nrows, _p(ro), _p(rd),
+                                _stream(c2w.device)), "nerf_get_rays")
+    return ro, rd
+
+
+def posenc(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    x = _gpu_f32(x, "x")
+    d = x.shape[-1]
+    L = int(freqs.numel())
+    out = torch.empty(x.shape[:-1] + (d * (1 + 2 * L),), dtype=torch.float32, device=x.device)
+    n = x.numel() // d if d else 0
+    fr = _gpu_f32(freqs, "freq_bands") if L else None
+    with torch.cuda.device(x.device):
+        check(lib.nerf_posenc(n, d, L, _p(fr), _p(x), _p(out), _stream(x.device)), "nerf_posenc")
+    return out
+
+
+def place_samples(n_rays: int, near, far, n_samples: int, lindisp: bool, device: torch.device,
+                  z_vals_override: Optional[torch.Tensor] = None,
+                  t_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """z_vals [n_rays, S]: linspace in depth/disparity (or the override) plus optional jitter."""
+    near_t = far_t = None
+    near_s = far_s = 0.0
+    if z_vals_override is not None:
+        zov = _gpu_f32(z_vals_override, "z_vals_override")
+        if zov.dim() != 2 or zov.shape[0] != n_rays:
+            raise ValueError(f"z_vals_override must be [N_rays, S], got {tuple(zov.shape)}")
+        S = zov.shape[1]
+        device = zov.device
+    else:
+        zov = None
+        S = int(n_samples)
+
+        def scal(v, nm):
+            if torch.is_tensor(v):
+                if v.numel() == 1:
+                    return float(v), None
+                vt = _gpu_f32(v.to(device), nm).reshape(-1)
+                if vt.numel() != n_rays:
+                    raise ValueError(f"{nm} must be a scalar or have one value per ray")
+                return 0.0, vt
+            return float(v), None
+        near_s, near_t = scal(near, "near")
+        far_s, far_t = scal(far, "far")
+    if t_rand is not None:
+        t_rand = _gpu_f32(t_rand, "t_rand")
+        if tuple(t_rand.shape) != (n_rays, S):
+            raise ValueError(f"t_rand must be [{n_rays}, {S}], got {tuple(t_rand.shape)}")
+    z = torch.empty((n_rays, S), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        check(lib.nerf_place_samples(n_rays, S, near_s, far_s, _p(near_t), _p(far_t), int(bool(lindisp)),
+                                     _p(zov), _p(t_rand), _p(z), _stream(device)), "nerf_place_samples")
+    return z
+
+
+# ---------------------------------------------------------------------------
+# compositing
+# ---------------------------------------------------------------------------
+
+class _Composite(torch.autograd.Function):
+    """raw [N,S,4], z [N,S] -> rgb_map, depth_map, disp_map, acc_map, weights, alpha."""
+
+    @staticmethod
+    def forward(ctx, raw, z, white_bkgd: bool):
+        raw = _gpu_f32(raw, "raw")
+        z = _gpu_f32(z, "z_vals")
+        N, S = z.shape
+        if raw.shape != (N, S, 4):
+            raise ValueError(f"raw must be [{N},{S},4], got {tuple(raw.shape)}")
+        dev = raw.device
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((N,), dtype=torch.float32, device=dev)
+        disp = torch.empty((N,), dtype=torch.float32, device=dev)
+        acc = torch.empty((N,), dtype=torch.float32, device=dev)
+        weights = torch.empty((N, S), dtype=torch.float32, device=dev)
+        alpha = torch.empty((N, S), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.nerf_composite_fwd(N, S, _p(raw), _p(z), int(bool(white_bkgd)), _p(rgb), _p(depth),
+                                         _p(disp), _p(acc), _p(weights), _p(alpha), _stream(dev)),
+                  "nerf_composite_fwd")
+        ctx.save_for_backward(raw, z)
+        ctx.white = bool(white_bkgd)
+        return rgb, depth, disp, acc, weights, alpha
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_disp, g_acc, g_w, g_alpha):
+        raw, z = ctx.saved_tensors
+        N, S = z.shape
+        dev = raw.device
+
+        def prep(g, nm):
+            return None if g is None else _gpu_f32(g, nm)
+        g_rgb, g_depth, g_disp, g_acc = prep(g_rgb, "g_rgb"), prep(g_depth, "g_depth"), prep(g_disp, "g_disp"), prep(g_acc, "g_acc")
+        g_w, g_alpha = prep(g_w, "g_weights"), prep(g_alpha, "g_alpha")
+        d_raw = torch.empty_like(raw)
+        with torch.cuda.device(dev):
+            check(lib.nerf_composite_bwd(N, S, _p(raw), _p(z), int(ctx.white), _p(g_rgb), _p(g_depth), _p(g_disp),
+                                         _p(g_acc), _p(g_w), _p(g_alpha), _p(d_raw), _stream(dev)),
+                  "nerf_composite_bwd")
+        return d_raw, None, None
+
+
+def composite(raw: torch.Tensor, z_vals: torch.Tensor, white_bkgd: bool = False):
+    return _Composite.apply(raw, z_vals, white_bkgd)
+
+
+# ---------------------------------------------------------------------------
+# hierarchical sampling
+# ---------------------------------------------------------------------------
+
+def _rows(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
+    """2-D fp32 GPU tensor with unit inner stride; returns (tensor, row stride)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); nerf_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D [N_rays, n], got {tuple(t.shape)}")
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, N_samples: int, det: bool = False, *,
+               u: Optional[torch.Tensor] = None, return_inds: bool = False):
+    bins, bld = _rows(bins, "bins")
+    weights, wld = _rows(weights, "weights")
+    N, nb = bins.shape
+    if weights.shape[0] != N or weights.shape[1] != nb - 1:
+        raise ValueError(
+            f"sample_pdf needs len(bins) == len(weights) + 1 per ray (got bins {tuple(bins.shape)}, "
+            f"weights {tuple(weights.shape)}); the CDF has one more knot than there are weights")
+    dev = bins.device
+    if u is None and not det:
+        u = torch.rand((N, N_samples), dtype=torch.float32, device=dev)
+    if u is not None:
+        u = _gpu_f32(u, "u")
+        if tuple(u.shape) != (N, N_samples):
+            raise ValueError(f"u must be [{N}, {N_samples}], got {tuple(u.shape)}")
+    samples = torch.empty((N, N_samples), dtype=torch.float32, device=dev)
+    inds = torch.empty((N, N_samples), dtype=torch.int32, device=dev) if return_inds else None
+    with torch.cuda.device(dev):
+        check(lib.nerf_sample_pdf(N, nb, _p(bins), bld, _p(weights), wld, int(N_samples), _p(u), _p(samples),
+                                  _p(inds), _stream(dev)), "nerf_sample_pdf")
+    return (samples, inds) if return_inds else samples
+
+
+def sort_rows(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row-wise ascending sort of cat([a, b], -1)."""
+    a = _gpu_f32(a, "a")
+    nb = 0
+    if b is not None:
+        b = _gpu_f32(b, "b")
+        nb = b.shape[1]
+    N, na = a.shape
+    out = torch.empty((N, na + nb), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib.nerf_sort_rows(N, na, _p(a), nb, _p(b), _p(out), _stream(a.device)), "nerf_sort_rows")
+    return out
+
+
+def sample_merge(z_coarse: torch.Tensor, weights_coarse: torch.Tensor, N_fine: int, det: bool, *,
+                 u: Optional[torch.Tensor] = None, return_fine: bool = False):
+    """Coarse->fine glue in one launch: sort(cat(z_coarse, sample_pdf(mid(z), w[1:-1]+1e-5)))."""
+    zc = _gpu_f32(z_coarse.detach(), "z_coarse")
+    wc = _gpu_f32(weights_coarse.detach(), "weights_coarse")
+    N, Sc = zc.shape
+    if wc.shape != zc.shape:
+        raise ValueError("z_coarse and weights_coarse must have the same shape")
+    dev = zc.device
+    if u is None and not det:
+        u = torch.rand((N, N_fine), dtype=torch.float32, device=dev)
+    if u is not None:
+        u = _gpu_f32(u, "u")
+        if tuple(u.shape) != (N, N_fine):
+            raise ValueError(f"u must be [{N}, {N_fine}], got {tuple(u.shape)}")
+    out = torch.empty((N, Sc + N_fine), dtype=torch.float32, device=dev)
+    zf = torch.empty((N, N_fine), dtype=torch.float32, device=dev) if return_fine else None
+    with torch.cuda.device(dev):
+        check(lib.nerf_sample_merge(N, Sc, _p(zc), _p(wc), int(N_fine), _p(u), _p(out), _p(zf), _stream(dev)),
+              "nerf_sample_merge")
+    return (out, zf) if return_fine else out
+
+
+# ---------------------------------------------------------------------------
+# fused MLP
+# ---------------------------------------------------------------------------
+
+def mlp_pack(flat_params: torch.Tensor, precision: str) -> torch.Tensor:
+    flat = _gpu_f32(flat_params, "flat_params")
+    if flat.numel() != _C.NERF_MLP_NPARAMS:
+        raise ValueError(f"expected {_C.NERF_MLP_NPARAMS} parameters, got {flat.numel()}")
+    packed = torch.empty((int(lib.nerf_mlp_packed_bytes()),), dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device):
+        check(lib.nerf_mlp_pack(_p(flat), _C.PREC[precision], _p(packed), _stream(flat.device)), "nerf_mlp_pack")
+    return packed
+
+
+class _FusedMLP(torch.autograd.Function):
+    """(rays_o, rays_d, z) or (x_pts, x_views) + 24 parameter tensors -> raw [M,4]."""
+
+    @staticmethod
+    def forward(ctx, mode, a0, a1, a2, precision, packed, need_grad, *params):
+        dev = a0.device
+        if mode == "rays":
+            rays_o, rays_d, z = _gpu_f32(a0, "rays_o"), _gpu_f32(a1, "rays_d"), _gpu_f32(a2, "z_vals")
+            N, S = z.shape
+            M = N * S
+            out_shape = (N, S, 4)
+        else:
+            x_pts, x_views = _gpu_f32(a0, "x_pts_encoded"), _gpu_f32(a1, "x_views_encoded")
+            M = x_pts.numel() // 63
+            out_shape = x_pts.shape[:-1] + (4,)
+        raw = torch.empty(out_shape, dtype=torch.float32, device=dev)
+        saved = None
+        if need_grad:
+            saved = torch.empty((int(lib.nerf_mlp_saved_bytes(M)),), dtype=torch.uint8, device=dev)
+        prec = _C.PREC[precision]
+        with torch.cuda.device(dev):
+            if mode == "rays":
+                check(lib.nerf_mlp_fwd(N, S, _p(rays_o), _p(rays_d), _p(z), _p(packed), prec, _p(raw), _p(saved),
+                                       _stream(dev)), "nerf_mlp_fwd")
+            else:
+                check(lib.nerf_mlp_fwd_encoded(M, _p(x_pts), _p(x_views), _p(packed), prec, _p(raw), _p(saved),
+                                               _stream(dev)), "nerf_mlp_fwd_encoded")
+        ctx.M = M
+        ctx.prec = prec
+        ctx.shapes = [p.shape for p in params]
+        ctx.packed = packed
+        ctx.saved_acts = saved
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        if ctx.saved_acts is None:
+            raise RuntimeError("fused MLP forward ran without saving activations (no parameter required grad)")
+        d_raw = _gpu_f32(d_raw, "d_raw")
+        dev = d_raw.device
+        M = ctx.M
+        ws_bytes = int(lib.nerf_mlp_bwd_workspace_bytes(M))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        d_flat = torch.empty((_C.NERF_MLP_NPARAMS,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.nerf_mlp_bwd(M, _p(d_raw), _p(ctx.packed), ctx.prec, _p(ctx.saved_acts), _p(ws), ws_bytes,
+                                   _p(d_flat), _stream(dev)), "nerf_mlp_bwd")
+        ctx.saved_acts = None
+        grads = []
+        off = 0
+        for shp in ctx.shapes:
+            n = 1
+            for s in shp:
+                n *= s
+            grads.append(d_flat[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None, None, None, None, *grads)
+
+
+def fused_mlp_rays(rays_o, rays_d, z_vals, precision: str, packed: torch.Tensor, params: Sequence[torch.Tensor]):
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _FusedMLP.apply("rays", rays_o, rays_d, z_vals, precision, packed, need_grad, *params)
+
+
+def fused_mlp_encoded(x_pts, x_views, precision: str, packed: torch.Tensor, params: Sequence[torch.Tensor]):
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _FusedMLP.apply("encoded", x_pts, x_views, None, precision, packed, need_grad, *params)
+
+
+# ---------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------
+
+def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+              lr: float, beta1: float, beta2: float, eps: float, step: int, grad_scale: float = 1.0) -> None:
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"{nm} must be a contiguous fp32 GPU tensor")
+    n = params.numel()
+    if not (grads.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n):
+        raise ValueError("adam_step: size mismatch")
+    with torch.cuda.device(params.device):
+        check(lib.nerf_adam_step(n, _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), float(lr), float(beta1),
+                                 float(beta2), float(eps), int(step), float(grad_scale), _stream(params.device)),
+              "nerf_adam_step")

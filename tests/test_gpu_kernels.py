@@ -1,0 +1,327 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (ctypes), against the CPU
+oracle on the same seeded inputs and against the committed golden vectors.
+
+Tolerances (stated per test): integer/index/sort results are bit-exact; fp32 kernels agree with
+the oracle to a few ulp (different exp/sin implementations and summation order); the bf16/fp16
+MFMA MLP agrees to the operand precision.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import O, T, amd_model, maxabs
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import nerf_amd
+    return nerf_amd
+
+
+# ---------------------------------------------------------------------------
+def test_library_loaded(amd):
+    from nerf_amd import _C
+    assert _C.lib.nerf_version() == 100
+    assert torch.cuda.is_available()
+
+
+def test_no_cpu_fallback(amd):
+    from nerf_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.get_rays(4, 4, 5.0, torch.eye(4))
+    with pytest.raises(RuntimeError):
+        amd.sample_pdf(torch.rand(2, 5), torch.rand(2, 4), 8, det=True)
+
+
+# ---------------------------------------------------------------------------
+def test_get_rays(amd, golden):
+    g = golden("f1_get_rays")
+    for nm in ("identity", "sph40"):
+        c2w = T(g[nm + "_c2w"], DEV)
+        ro, rd = amd.get_rays(8, 8, 5.0, c2w)
+        assert ro.shape == (8, 8, 3) and rd.is_contiguous() and rd.device.type == "cuda"
+        assert maxabs(ro, T(g[nm + "_o8"])) == 0.0
+        assert maxabs(rd, T(g[nm + "_d8"])) < 2e-7          # fp32, one division + sqrt differ by <= 1 ulp
+        ro, rd = amd.get_rays(800, 800, float(g["focal800"]), c2w)
+        assert maxabs(rd[392:408, 792:800], T(g[nm + "_d800_crop"])) < 2e-7
+        assert maxabs(rd[:4, :4], T(g[nm + "_d800_corner"])) < 2e-7
+        assert maxabs(rd.double().sum(dim=(0, 1)), T(g[nm + "_d800_sum"])) < 1e-2
+        assert torch.allclose(rd.norm(dim=-1), torch.ones(800, 800, device=DEV), atol=1e-6)
+        # row-block form used for sharding: rows 100..149 equal the slice of the full frame
+        ro_b, rd_b = amd.get_rays(800, 800, float(g["focal800"]), c2w, row0=100, nrows=50)
+        assert torch.equal(rd_b, rd[100:150]) and torch.equal(ro_b, ro[100:150])
+        # [3,4] pose and an odd, non-multiple-of-4 frame (scalar tail path)
+        ro3, rd3 = amd.get_rays(7, 9, 5.0, c2w[:3].contiguous())
+        oro, ord_ = O.get_rays(7, 9, 5.0, c2w.cpu())
+        assert maxabs(rd3, ord_) < 2e-7 and maxabs(ro3, oro) == 0.0
+    # reference known answers (tests/test_ray_utils.py:56-143)
+    ro, rd = amd.get_rays(4, 4, 5.0, torch.eye(4, device=DEV))
+    assert torch.all(ro == 0)
+    assert torch.allclose(rd[2, 2].cpu(), torch.tensor([0.0, 0.0, -1.0]), atol=1e-6)
+    tl = torch.tensor([-0.4, -0.4, -1.0]); tl = tl / tl.norm()
+    assert torch.allclose(rd[0, 0].cpu(), tl, atol=1e-6)
+
+
+def test_posenc(amd, golden):
+    g = golden("f2_posenc")
+    x = T(g["x"], DEV)
+    e10 = amd.PositionalEncoder(3, 10).to(DEV)(x)
+    e4 = amd.PositionalEncoder(3, 4).to(DEV)(x)
+    el = amd.PositionalEncoder(3, 5, log_sampling=False).to(DEV)(x)
+    # fp32 sin/cos of the same fp32 argument: <= 1e-6 abs (arguments reach 3e3 rad)
+    assert maxabs(e10, T(g["e10"])) < 1e-6 and maxabs(e4, T(g["e4"])) < 1e-6 and maxabs(el, T(g["elin5"])) < 1e-6
+    assert amd.PositionalEncoder(3, 10).output_dims == 63 and amd.PositionalEncoder(2, 5).output_dims == 22
+    e0 = amd.PositionalEncoder(3, 0).to(DEV)(x)
+    assert torch.equal(e0, x)
+    xm = torch.randn(5, 7, 3, device=DEV)
+    assert amd.PositionalEncoder(3, 10).to(DEV)(xm).shape == (5, 7, 63)
+    p = torch.tensor([[np.pi / 2]], dtype=torch.float32, device=DEV)
+    out = amd.PositionalEncoder(1, 1).to(DEV)(p).cpu()
+    assert torch.allclose(out, torch.tensor([[np.pi / 2, 1.0, 0.0]]), atol=1e-7)
+
+
+def test_place_samples(amd):
+    from nerf_amd import ops
+    N = 33
+    for S in (64, 192, 5):
+        for lind in (False, True):
+            z = ops.place_samples(N, 2.0, 6.0, S, lind, torch.device(DEV))
+            zo = O.place_samples(N, 2.0, 6.0, S, lind)
+            assert maxabs(z, zo) < 1e-6           # fp32, <= 2 ulp at z ~ 6
+            tr = torch.rand(N, S)
+            z = ops.place_samples(N, 2.0, 6.0, S, lind, torch.device(DEV), t_rand=tr.to(DEV))
+            assert maxabs(z, O.place_samples(N, 2.0, 6.0, S, lind, t_rand=tr)) < 1e-6
+    # per-ray bounds and the override + jitter path (fine pass of training)
+    near, far = torch.rand(N, 1) + 1.5, torch.rand(N, 1) + 5.0
+    z = ops.place_samples(N, near.to(DEV), far.to(DEV), 64, False, torch.device(DEV))
+    assert maxabs(z, O.place_samples(N, near, far, 64, False)) < 1e-6
+    zov, _ = torch.sort(torch.rand(N, 192) * 4 + 2, -1)
+    tr = torch.rand(N, 192)
+    z = ops.place_samples(N, 0, 0, 0, False, torch.device(DEV), z_vals_override=zov.to(DEV), t_rand=tr.to(DEV))
+    assert maxabs(z, O.place_samples(N, 0, 0, 0, False, z_vals_override=zov, t_rand=tr)) < 1e-6
+
+
+# ---------------------------------------------------------------------------
+def test_composite_golden(amd, golden):
+    from nerf_amd import ops
+    g = golden("f4_composite")
+    raw, z = T(g["raw"], DEV), T(g["z"], DEV)
+    for wb in (0, 1):
+        rr = raw.clone().requires_grad_(True)
+        rgb, depth, disp, acc, w, alpha = ops.composite(rr, z, bool(wb))
+        # forward: 1e-5 abs on maps of O(1..6) magnitude, 1e-6 on per-sample quantities
+        assert maxabs(rgb, T(g[f"rgb_map_wb{wb}"])) < 1e-5
+        assert maxabs(depth, T(g[f"depth_map_wb{wb}"])) < 1e-5
+        assert maxabs(acc, T(g[f"acc_map_wb{wb}"])) < 1e-5
+        d_ref = T(g[f"disp_map_wb{wb}"])
+        assert torch.allclose(disp.cpu(), d_ref, rtol=1e-5, atol=1e-6)
+        assert maxabs(w, T(g[f"weights_wb{wb}"])) < 2e-6
+        assert maxabs(alpha, T(g[f"alpha_wb{wb}"])) < 2e-6
+        # backward: 1e-4 relative to the largest gradient entry
+        loss = (rgb * T(g[f"g_rgb_wb{wb}"], DEV)).sum() + (depth * T(g[f"g_depth_wb{wb}"], DEV)).sum() \
+            + (acc * T(g[f"g_acc_wb{wb}"], DEV)).sum()
+        (gr,) = torch.autograd.grad(loss, rr, retain_graph=True)
+        ref = T(g[f"draw_wb{wb}"])
+        assert maxabs(gr, ref) < 1e-4 * ref.abs().max().item()
+        loss2 = loss + (w * T(g[f"g_w_wb{wb}"], DEV)).sum()
+        (gr2,) = torch.autograd.grad(loss2, rr)
+        ref2 = T(g[f"draw_withw_wb{wb}"])
+        assert maxabs(gr2, ref2) < 1e-4 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("S", [1, 7, 64, 65, 128, 192, 256, 300, 700])
+def test_composite_sizes(amd, S):
+    """Ragged and multi-chunk sample counts, all outputs and all cotangents incl. disp and alpha."""
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(S)
+    N = 37
+    raw = torch.randn(N, S, 4, generator=gen)
+    raw[..., 3] = raw[..., 3] * 3 + 0.5
+    z, _ = torch.sort(torch.rand(N, S, generator=gen) * 4 + 2, -1)
+    gs = [torch.randn(N, 3, generator=gen), torch.randn(N, generator=gen), torch.randn(N, generator=gen) * 0.1,
+          torch.randn(N, generator=gen), torch.randn(N, S, generator=gen), torch.randn(N, S, generator=gen)]
+    rr = raw.clone().requires_grad_(True)
+    o = O.composite(rr, z, True)
+    outs_ref = [o["rgb_map"], o["depth_map"], o["disp_map"], o["acc_map"], o["weights"], o["alpha"]]
+    (g_ref,) = torch.autograd.grad(sum((a * b).sum() for a, b in zip(outs_ref, gs)), rr)
+    rg = raw.to(DEV).requires_grad_(True)
+    outs = ops.composite(rg, z.to(DEV), True)
+    for a, b in zip(outs, outs_ref):
+        assert torch.allclose(a.cpu(), b.detach(), rtol=2e-5, atol=1e-5)
+    (g_gpu,) = torch.autograd.grad(sum((a * b.to(DEV)).sum() for a, b in zip(outs, gs)), rg)
+    assert maxabs(g_gpu, g_ref) < 2e-4 * g_ref.abs().max().item()
+
+
+def test_composite_empty(amd):
+    from nerf_amd import ops
+    outs = ops.composite(torch.zeros(0, 64, 4, device=DEV), torch.zeros(0, 64, device=DEV), False)
+    assert outs[0].shape == (0, 3) and outs[4].shape == (0, 64)
+
+
+# ---------------------------------------------------------------------------
+def _margin_mask(cdf, u, tol=1e-6):
+    """uniforms farther than tol from every CDF knot (index is then insensitive to 1-ulp CDF noise)"""
+    d = (u[:, :, None].double() - cdf[:, None, :].double()).abs().min(-1).values
+    return d > tol
+
+
+def test_sample_pdf_golden(amd, golden):
+    from nerf_amd import ops
+    g = golden("f6_sample_pdf")
+    bins, w, u = T(g["bins"], DEV), T(g["weights"], DEV), T(g["u"], DEV)
+    cdf = T(g["cdf"])
+    s, inds = ops.sample_pdf(bins, w, 128, det=False, u=u, return_inds=True)
+    ok = _margin_mask(cdf, T(g["u"]))
+    assert ok.float().mean() > 0.999
+    # indices: EXACT wherever the uniform is not within 1e-6 of a knot; the rest is counted
+    mism = (inds.cpu() != T(g["inds_rand"]))
+    assert not (mism & ok).any()
+    assert mism.sum().item() <= 4
+    same = ~mism
+    assert maxabs(s.cpu()[same], T(g["samples_rand"])[same]) < 2e-5    # fp32 interpolation of values in [2,6]
+    s, inds = ops.sample_pdf(bins, w, 128, det=True, return_inds=True)
+    udet = torch.linspace(0, 1, 128).expand(256, 128)
+    ok = _margin_mask(cdf, udet)
+    mism = (inds.cpu() != T(g["inds_det"]))
+    assert not (mism & ok).any() and mism.sum().item() <= 4
+    assert maxabs(s.cpu()[~mism], T(g["samples_det"])[~mism]) < 2e-5
+    # drop-in signature; properties of the reference's tests with the real calling convention
+    s2 = amd.sample_pdf(bins, w, 128, det=True)
+    assert torch.equal(s2, s)
+    assert s.shape == (256, 128)
+    assert torch.all(s >= bins.min(-1, keepdim=True).values - 1e-6)
+    assert torch.all(s <= bins.max(-1, keepdim=True).values + 1e-6)
+    assert torch.all(torch.diff(s[2]) >= -1e-6)
+    sr = amd.sample_pdf(bins, w, 128, det=False)
+    assert sr.shape == (256, 128) and torch.isfinite(sr).all()
+    with pytest.raises(ValueError):
+        amd.sample_pdf(bins, T(g["bins"], DEV), 128)      # equal lengths: the reference's own tests' mistake
+
+
+@pytest.mark.parametrize("nb,ns", [(2, 3), (5, 10), (63, 128), (64, 64), (130, 200), (1000, 77)])
+def test_sample_pdf_sizes(amd, nb, ns):
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(nb * 1000 + ns)
+    N = 19
+    bins, _ = torch.sort(torch.rand(N, nb, generator=gen) * 4 + 2, -1)
+    w = torch.rand(N, nb - 1, generator=gen) ** 3
+    u = torch.rand(N, ns, generator=gen)
+    so, io, cdf = O.sample_pdf(bins, w, ns, u=u, return_inds=True)
+    s, inds = ops.sample_pdf(bins.to(DEV), w.to(DEV), ns, u=u.to(DEV), return_inds=True)
+    ok = _margin_mask(cdf, u)
+    mism = inds.cpu() != io.to(torch.int32)
+    assert not (mism & ok).any()
+    assert maxabs(s.cpu()[~mism], so[~mism]) < 5e-5
+    # strided views (weights[..., 1:-1] style) take the row-stride path
+    wfull = torch.rand(N, nb + 1, generator=gen).to(DEV)
+    s_view = ops.sample_pdf(bins.to(DEV), wfull[:, 1:-1], ns, u=u.to(DEV))
+    s_cont = ops.sample_pdf(bins.to(DEV), wfull[:, 1:-1].contiguous(), ns, u=u.to(DEV))
+    assert torch.equal(s_view, s_cont)
+
+
+def test_sort_and_merge(amd, golden):
+    from nerf_amd import ops
+    g = golden("f7_merge")
+    zc, zf = T(g["z_coarse"], DEV), T(g["z_fine"], DEV)
+    out = ops.sort_rows(zc, zf)
+    assert torch.equal(out.cpu(), T(g["z_sorted"]))                       # bit-exact
+    for n in (1, 3, 64, 100, 192, 257, 500, 1024):
+        x = torch.randn(11, n)
+        x[0, : n // 2] = x[0, 0]                                          # duplicates
+        assert torch.equal(ops.sort_rows(x.to(DEV)).cpu(), torch.sort(x, -1).values)
+    # fused glue == separate kernels (bit-exact) and == oracle (fp32 tolerance)
+    gen = torch.Generator().manual_seed(5)
+    N = 200
+    zc, _ = torch.sort(torch.rand(N, 64, generator=gen) * 4 + 2, -1)
+    wc = torch.rand(N, 64, generator=gen) ** 4
+    u = torch.rand(N, 128, generator=gen)
+    for uu in (u, None):
+        det = uu is None
+        zm = 0.5 * (zc[:, 1:] + zc[:, :-1])
+        sf = ops.sample_pdf(zm.to(DEV), (wc[:, 1:-1] + 1e-5).to(DEV), 128, det=det, u=None if det else uu.to(DEV))
+        ref = ops.sort_rows(zc.to(DEV), sf)
+        fused, zfine = ops.sample_merge(zc.to(DEV), wc.to(DEV), 128, det, u=None if det else uu.to(DEV),
+                                        return_fine=True)
+        assert torch.equal(fused, ref) and torch.equal(zfine, sf)
+        orc = O.merge_samples(zc, wc, 128, det, uu)
+        # a sample whose CDF index differs by one moves by a bin width; compare sorted rows loosely
+        # in count, tightly in value
+        diff = (fused.cpu() - orc).abs()
+        assert (diff > 5e-5).float().mean() < 1e-4
+    assert torch.all(torch.diff(fused, dim=-1) >= 0)
+
+
+# ---------------------------------------------------------------------------
+def _raw_tolerance(precision):
+    # raw outputs are O(0.1); operand rounding 2^-8 (bf16) / 2^-11 (fp16) through 10 layers
+    return {"bf16": 3e-3, "fp16": 4e-4}[precision]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_mlp_forward_golden(amd, golden, precision):
+    g = golden("f3_mlp")
+    pts, vd, raw_ref = T(g["pts"]), T(g["viewdirs"]), T(g["raw"])
+    model = amd_model(O.init_params(0), precision)
+    tol = _raw_tolerance(precision)
+    with torch.no_grad():
+        # fused mode: a ray per point, z = 0 puts the sample on the origin; rays_d = unit view direction
+        raw = model.forward_rays(pts.to(DEV), vd.to(DEV), torch.zeros(pts.shape[0], 1, device=DEV))
+        assert raw.shape == (4096, 1, 4)
+        err = maxabs(raw.view(-1, 4), raw_ref)
+        assert err < tol, err
+        # literal NeRF.forward(x_pts_encoded, x_views_encoded) signature
+        ep, ev = O.positional_encode(pts, 10), O.positional_encode(vd, 4)
+        raw2 = model(ep.to(DEV), ev.to(DEV))
+        assert raw2.shape == (4096, 4)
+        err2 = maxabs(raw2, raw_ref)
+        assert err2 < tol, err2
+        # ragged sizes (not a multiple of the 256-sample tile), and a tiny call
+        for n in (1, 31, 257, 1000):
+            r = model.forward_rays(pts[:n].to(DEV), vd[:n].to(DEV), torch.zeros(n, 1, device=DEV))
+            assert maxabs(r.view(-1, 4), raw_ref[:n]) < tol
+    with pytest.raises(ValueError):
+        model(ep.to(DEV))
+    sd = model.state_dict()
+    assert list(sd.keys()) == [k for k, _ in O.param_shapes()]
+
+
+def test_mlp_unsupported_arch(amd):
+    m = amd.NeRF(D=4, W=64, skips=[2]).to(DEV)
+    assert m.pts_linears[3].in_features == 64 + 63
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(8, 63, device=DEV), torch.zeros(8, 27, device=DEV))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_render_e2e_golden(amd, golden, precision):
+    """Config 1 (1024 rays, 64+128, deterministic) against the reference's maps.
+
+    The last interval is 1e10 long, so alpha_last is a step function of raw_sigma_last; at random
+    init 1-2 % of rays have |raw_sigma_last| below the operand rounding error and may flip.  Maps
+    are compared at 1e-3 abs on the rays whose coarse AND fine reference |raw_sigma_last| exceeds
+    10x the precision's observed raw-sigma error, and the masked share is bounded."""
+    g = golden("f8_e2e_render")
+    ro, rd = T(g["rays_o"], DEV), T(g["rays_d"], DEV)
+    mc, mf = amd_model(O.init_params(0), precision), amd_model(O.init_params(1), precision)
+    pe, pv = amd.PositionalEncoder(3, 10).to(DEV), amd.PositionalEncoder(3, 4).to(DEV)
+    delta = {"bf16": 3e-3, "fp16": 4e-4}[precision]   # 10x the observed raw-sigma error of the mode
+    for lind in (0, 1):
+        for wb in (0, 1):
+            tag = f"l{lind}w{wb}"
+            with torch.no_grad():
+                c, f = amd.render_hierarchical(mc, mf, pe, pv, ro, rd, 2.0, 6.0, 64, 128, rand=False, det=True,
+                                               lindisp=bool(lind), white_bkgd=bool(wb))
+            assert set(c.keys()) == {"rgb_map", "depth_map", "disp_map", "acc_map", "weights", "z_vals", "alpha",
+                                     "raw_sigma"}
+            assert f["z_vals"].shape == (1024, 192) and f["raw_sigma"].shape == (1024, 192)
+            okc = torch.from_numpy(np.abs(g[f"c_sigma_last_{tag}"]) > delta)
+            okf = okc & torch.from_numpy(np.abs(g[f"f_sigma_last_{tag}"]) > delta)
+            assert okf.float().mean() > (0.8 if precision == "bf16" else 0.95)
+            for k in ("rgb_map", "depth_map", "acc_map"):
+                ec = maxabs(c[k].cpu()[okc], T(g[f"c_{k}_{tag}"])[okc])
+                ef = maxabs(f[k].cpu()[okf], T(g[f"f_{k}_{tag}"])[okf])
+                assert ec < 1e-3 and ef < 1e-3, (k, tag, ec, ef)
