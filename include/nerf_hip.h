@@ -76,7 +76,8 @@ int nerf_place_samples(int64_t n_rays, int S, float near_s, float far_s, const f
  * alpha compositing forward -- models/nerf.py:430-472.
  * raw [n_rays,S,4] (16-byte aligned), z [n_rays,S] ->
  * rgb_map [n_rays,3], depth/disp/acc [n_rays], weights [n_rays,S],
- * alpha [n_rays,S] (nullable).  1 <= S <= 1024.
+ * alpha [n_rays,S] (nullable).  2 <= S <= 1024 (with one sample the reference's own
+ * interval list is empty and its outputs degenerate).
  */
 int nerf_composite_fwd(int64_t n_rays, int S, const float *raw, const float *z, int white_bkgd,
                        float *rgb_map, float *depth_map, float *disp_map, float *acc_map, float *weights,

@@ -186,8 +186,9 @@ static inline unsigned ray_grid(int64_t n_rays) {
 extern "C" int nerf_composite_fwd(int64_t n_rays, int S, const float* raw, const float* z, int white_bkgd,
                                   float* rgb_map, float* depth_map, float* disp_map, float* acc_map,
                                   float* weights, float* alpha, void* stream) {
+    NERF_REQUIRE(n_rays >= 0 && S >= 2 && S <= 1024, NERF_E_SHAPE);
+    if (n_rays == 0) return NERF_OK;
     NERF_REQUIRE(raw && z && rgb_map && depth_map && disp_map && acc_map && weights, NERF_E_NULL);
-    NERF_REQUIRE(n_rays >= 0 && S >= 1 && S <= 1024, NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(raw, 16), NERF_E_ALIGN);
     if (n_rays == 0) return NERF_OK;
     const dim3 grid(nerf::ray_grid(n_rays)), block(256);
@@ -210,8 +211,9 @@ extern "C" int nerf_composite_bwd(int64_t n_rays, int S, const float* raw, const
                                   const float* g_rgb, const float* g_depth, const float* g_disp,
                                   const float* g_acc, const float* g_weights, const float* g_alpha,
                                   float* d_raw, void* stream) {
+    NERF_REQUIRE(n_rays >= 0 && S >= 2 && S <= 1024, NERF_E_SHAPE);
+    if (n_rays == 0) return NERF_OK;
     NERF_REQUIRE(raw && z && d_raw, NERF_E_NULL);
-    NERF_REQUIRE(n_rays >= 0 && S >= 1 && S <= 1024, NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(d_raw, 16), NERF_E_ALIGN);
     if (n_rays == 0) return NERF_OK;
     const dim3 grid(nerf::ray_grid(n_rays)), block(256);
