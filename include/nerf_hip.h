@@ -157,9 +157,14 @@ int nerf_mlp_fwd_encoded(int64_t M, const float *x_pts, const float *x_views, co
                          int precision, float *raw, void *saved, void *stream);
 
 /* Backward: d_raw [M,4] -> d_params flat fp32 [NERF_MLP_NPARAMS] (overwritten,
- * not accumulated).  saved is what nerf_mlp_fwd wrote for the same samples. */
+ * not accumulated).  saved is what nerf_mlp_fwd wrote for the same samples.
+ * grad_scale (nullable): one device float s; the incoming gradient is multiplied
+ * by s before it is rounded to 16 bits and the result divided by s, which keeps
+ * small gradients inside the fp16 range (a power of two leaves bf16/fp16 mantissas
+ * untouched). */
 int nerf_mlp_bwd(int64_t M, const float *d_raw, const void *packed, int precision, const void *saved,
-                 void *workspace, int64_t workspace_bytes, float *d_params, void *stream);
+                 const float *grad_scale, void *workspace, int64_t workspace_bytes, float *d_params,
+                 void *stream);
 
 /* Adam on a flat fp32 buffer -- the optimizer.step() of scripts/train_nerf.py:336
  * (torch.optim.Adam, no weight decay, no amsgrad).  step is 1-based. */

@@ -39,7 +39,7 @@ _SIGS = {
     "nerf_mlp_bwd_workspace_bytes": (c_int64, [c_int64]),
     "nerf_mlp_fwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P, P]),
     "nerf_mlp_fwd_encoded": (c_int, [c_int64, P, P, P, c_int, P, P, P]),
-    "nerf_mlp_bwd": (c_int, [c_int64, P, P, c_int, P, P, c_int64, P, P]),
+    "nerf_mlp_bwd": (c_int, [c_int64, P, P, c_int, P, P, P, c_int64, P, P]),
     "nerf_adam_step": (c_int, [c_int64, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
 }
 for _name, (_res, _args) in _SIGS.items():

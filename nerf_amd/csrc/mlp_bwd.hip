@@ -1,7 +1,519 @@
-// placeholder until the backward kernels land
-#include "mlp_common.hpp"
-extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) { (void)n_samples; return 0; }
+// Backward of the fused MLP (the autograd of src/nerf_project/models/nerf.py:173-209 with respect
+// to the 24 parameter tensors), in three launches:
+//
+//  1. mlp_dgrad_kernel -- the backward-data chain.  Same structure as the forward: a wave owns 32
+//     samples, dZ of a layer (features in registers, samples on lanes) is the MFMA B operand of the
+//     next product dH_in = W^T dZ, weights stream through the LDS ring from the transposed block
+//     stream.  ReLU masks come from the saved activations.  Every layer's dZ is written out (16 bit)
+//     in [32 samples][16 positions] units for the weight-gradient pass.
+//  2. mlp_wgrad_kernel -- dW = sum over samples dZ x In^T: 14 GEMMs whose contraction index is the
+//     sample.  Units are DMA-copied into LDS as they are and read back with ds_read_b64_tr_b16,
+//     which delivers the [feature][8 samples] fragments the MFMA wants.  The sample axis is
+//     split across workgroups; each writes an fp32 partial block.  HBM-bound: every saved unit and
+//     every dZ unit is read once (a few are read twice), 128 flop per byte.
+//  3. mlp_reduce_kernel -- sums the partial blocks in fixed order (bitwise reproducible) and
+//     scatters them from slot order to the flat state_dict-order gradient buffer.
+#include <type_traits>
+#include "mlp_chain.hpp"
+
+namespace nerf {
+namespace mlp {
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient GEMM table
+// ------------------------------------------------------------------------------------------------
+struct GemmDesc {
+    int dz_layer, a_ks0, a_nks;     // rows: k-steps [a_ks0, a_ks0 + a_nks) of dZ[dz_layer]
+    int b_tensor, b_nks;            // cols: saved tensor, all its k-steps
+    int has_bias;                   // this GEMM also produces the bias gradient of its rows
+};
+constexpr int NGEMM = 14;
+constexpr GemmDesc GEMMS[NGEMM] = {
+    {0, 0, 16, SV_PE, 4, 1},          //  0: pts_linears.0
+    {1, 0, 16, SV_H0 + 0, 16, 1},     //  1: pts_linears.1
+    {2, 0, 16, SV_H0 + 1, 16, 1},     //  2
+    {3, 0, 16, SV_H0 + 2, 16, 1},     //  3
+    {4, 0, 16, SV_H0 + 3, 16, 1},     //  4
+    {5, 0, 16, SV_PE, 4, 0},          //  5: pts_linears.5[:, :63]
+    {5, 0, 16, SV_H0 + 4, 16, 1},     //  6: pts_linears.5[:, 63:]
+    {6, 0, 16, SV_H0 + 5, 16, 1},     //  7: pts_linears.6
+    {7, 0, 16, SV_H0 + 6, 16, 1},     //  8: pts_linears.7
+    {8, 0, 16, SV_H0 + 7, 16, 1},     //  9: feature_linear
+    {8, 16, 1, SV_H0 + 7, 16, 1},     // 10: sigma_linear (row 0 of the unit)
+    {9, 0, 8, SV_F, 16, 1},           // 11: rgb_layers.0[:, :256]
+    {9, 0, 8, SV_VPE, 2, 0},          // 12: rgb_layers.0[:, 256:]
+    {10, 0, 1, SV_G, 8, 1},           // 13: rgb_layers.2 (rows 0..2)
+};
+// partial block of GEMM g: [a_nks*16][b_nks*16] floats, then a_nks*16 bias floats
+constexpr int gemm_out_floats(int g) { return GEMMS[g].a_nks * 16 * GEMMS[g].b_nks * 16 + GEMMS[g].a_nks * 16; }
+constexpr int gemm_out_off(int g) { int o = 0; for (int i = 0; i < g; ++i) o += gemm_out_floats(i); return o; }
+constexpr int gemm_stage_kb(int g) { return GEMMS[g].a_nks + GEMMS[g].b_nks; }
+constexpr int TOTAL_STAGE_KB = [] { int s = 0; for (int g = 0; g < NGEMM; ++g) s += gemm_stage_kb(g); return s; }();
+
+constexpr int WGRAD_TARGET_JOBS = 512;     // about two workgroups' worth of jobs per CU
+
+struct JobTable {
+    int splits[NGEMM];       // sample-axis splits of each GEMM
+    int job0[NGEMM + 1];     // first job of each GEMM
+    int64_t part_off[NGEMM]; // float offset of GEMM g's first partial block in the partial buffer
+};
+
+static JobTable make_jobs(int64_t n_wt) {
+    JobTable t;
+    int64_t off = 0;
+    t.job0[0] = 0;
+    for (int g = 0; g < NGEMM; ++g) {
+        int64_t s = ((int64_t)WGRAD_TARGET_JOBS * gemm_stage_kb(g) + TOTAL_STAGE_KB / 2) / TOTAL_STAGE_KB;
+        if (s < 1) s = 1;
+        if (s > n_wt) s = n_wt;
+        t.splits[g] = (int)s;
+        t.job0[g + 1] = t.job0[g] + (int)s;
+        t.part_off[g] = off;
+        off += s * gemm_out_floats(g);
+    }
+    return t;
+}
+static int64_t partial_floats(const JobTable& t) {
+    return t.part_off[NGEMM - 1] + (int64_t)t.splits[NGEMM - 1] * gemm_out_floats(NGEMM - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. backward-data chain
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    int64_t M, n_tiles;
+    const float* d_raw;      // [M,4]
+    const char* packed;
+    const char* saved;
+    char* dz;                // DZ_UNITS KiB per wave tile
+    const float* scale;      // nullable: gradients are multiplied by *scale on entry (fp16 range)
+};
+
+template <int PREC>
+__device__ __forceinline__ typename Prec<PREC>::frag load_unit_frag(const char* base, int ks0, int nks, int64_t n_wt,
+                                                                    int64_t wt, int ks, int lane_off) {
+    return *reinterpret_cast<const typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off);
+}
+
+template <int PREC>
+__device__ __forceinline__ void store_unit_frag(char* base, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
+                                                int lane_off, const typename Prec<PREC>::frag& f) {
+    *reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
+}
+
+// accumulator tile (gradient w.r.t. a post-ReLU activation) -> masked 16-bit fragments
+template <int PREC, bool MASK>
+__device__ __forceinline__ void grad_to_frags(const f32x16& acc, const typename Prec<PREC>::frag& h0,
+                                              const typename Prec<PREC>::frag& h1, typename Prec<PREC>::frag& f0,
+                                              typename Prec<PREC>::frag& f1) {
+    typedef typename Prec<PREC>::elem T;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = (!MASK || (float)h0[j] > 0.0f) ? acc[j] : 0.0f;
+        const float b = (!MASK || (float)h1[j] > 0.0f) ? acc[8 + j] : 0.0f;
+        f0[j] = (T)a;
+        f1[j] = (T)b;
+    }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdArgs a) {
+    typedef typename Prec<PREC>::frag frag;
+    typedef typename Prec<PREC>::elem T;
+    __shared__ __attribute__((aligned(16))) char lds[CHAIN_LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int lane_off = c * 32 + h * 16;
+    const float gscale = a.scale ? *a.scale : 1.0f;
+
+    Ring ring;
+    ring_init(ring, lds, a.packed + PACK_BWD_OFF, BWD_CHUNKS, lane, wave);
+    const int64_t n_wt = a.n_tiles * 8;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t wt = tile * 8 + wave;
+        const int64_t m = wt * WAVE_SAMPLES + c;
+        const bool valid = m < a.M;
+
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && h == 0) dr = reinterpret_cast<const float4*>(a.d_raw)[m];
+        dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale;
+
+        frag da[H_KS + 1], db[H_KS];
+        frag mk[2][2];
+
+        // dZ10: slots 0..2 = d rgb_raw (lane half 0, elements 0..2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) db[0][j] = (T)0.0f;
+        db[0][0] = (T)dr.x; db[0][1] = (T)dr.y; db[0][2] = (T)dr.z;
+        store_unit_frag<PREC>(a.dz, dz_ks0(10), DZ_KS[10], n_wt, wt, 0, lane_off, db[0]);
+
+        // generic masked step: acc tile mt of d(activation saved as tensor SV) -> out[2mt], out[2mt+1],
+        // stored as dZ of layer DZL
+        auto mask_pre = [&](auto SV, int nks) {
+            return [&, nks](int mt) {
+                constexpr int sv = decltype(SV)::value;
+                mk[mt & 1][0] = load_unit_frag<PREC>(a.saved, saved_ks0(sv), nks, n_wt, wt, 2 * mt, lane_off);
+                mk[mt & 1][1] = load_unit_frag<PREC>(a.saved, saved_ks0(sv), nks, n_wt, wt, 2 * mt + 1, lane_off);
+                return zero;
+            };
+        };
+        auto mask_epi = [&](auto DZL, frag* out) {
+            return [&, out](int mt, const f32x16& acc) {
+                constexpr int dzl = decltype(DZL)::value;
+                grad_to_frags<PREC, true>(acc, mk[mt & 1][0], mk[mt & 1][1], out[2 * mt], out[2 * mt + 1]);
+                store_unit_frag<PREC>(a.dz, dz_ks0(dzl), DZ_KS[dzl], n_wt, wt, 2 * mt, lane_off, out[2 * mt]);
+                store_unit_frag<PREC>(a.dz, dz_ks0(dzl), DZ_KS[dzl], n_wt, wt, 2 * mt + 1, lane_off, out[2 * mt + 1]);
+            };
+        };
+#define NERF_IC(N) std::integral_constant<int, N>()
+        // d0: dG = W_r2^T dZ10, masked by G > 0  -> dZ9 (8 k-steps) in da
+        run_layer<PREC, bwd_block0(0), 4, 1, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_G), G_KS), mask_epi(NERF_IC(9), da));
+        // d1: dF = W_r0[:, :256]^T dZ9 (feature_linear has no activation) -> dZ8[0..255] in db; sigma joins as k-step 16
+        run_layer<PREC, bwd_block0(1), 8, G_KS, 0>(ring, lds, da, da, [&](int) { return zero; },
+                                                  [&](int mt, const f32x16& acc) {
+            frag f0 = {}, f1 = {};
+            grad_to_frags<PREC, false>(acc, f0, f0, f0, f1);
+            db[2 * mt] = f0; db[2 * mt + 1] = f1;
+            store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, 2 * mt, lane_off, f0);
+            store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, 2 * mt + 1, lane_off, f1);
+        });
+        frag dsig;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsig[j] = (T)0.0f;
+        dsig[0] = (T)dr.w;                                   // slot 256 = sigma_raw (lane half 0, element 0)
+        store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, H_KS, lane_off, dsig);
+        // d2: dH7 = [W_f; w_sigma]^T dZ8, masked by H7 > 0 -> dZ7 in da
+        run_layer<PREC, bwd_block0(2), 8, H_KS, 1>(ring, lds, db, &dsig, mask_pre(NERF_IC(SV_H0 + 7), H_KS),
+                                                  mask_epi(NERF_IC(7), da));
+        // d3..d9: hidden layers 7, 6, 5 (H rows), 4, 3, 2, 1
+        run_layer<PREC, bwd_block0(3), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 6), H_KS), mask_epi(NERF_IC(6), db));
+        run_layer<PREC, bwd_block0(4), 8, H_KS, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_H0 + 5), H_KS), mask_epi(NERF_IC(5), da));
+        run_layer<PREC, bwd_block0(5), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 4), H_KS), mask_epi(NERF_IC(4), db));
+        run_layer<PREC, bwd_block0(6), 8, H_KS, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_H0 + 3), H_KS), mask_epi(NERF_IC(3), da));
+        run_layer<PREC, bwd_block0(7), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 2), H_KS), mask_epi(NERF_IC(2), db));
+        run_layer<PREC, bwd_block0(8), 8, H_KS, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_H0 + 1), H_KS), mask_epi(NERF_IC(1), da));
+        run_layer<PREC, bwd_block0(9), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 0), H_KS), mask_epi(NERF_IC(0), db));
+#undef NERF_IC
+        // The stream is padded to whole chunks; the pad blocks of the last chunk are never read, and
+        // the next pass enters a fresh chunk at its block 0.
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. weight-gradient GEMMs
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_STAGES = 3;
+constexpr int WG_STAGE_BYTES = 32 * 1024;     // up to 16 A units + 16 B units
+constexpr int WG_LDS_BYTES = WG_STAGES * WG_STAGE_BYTES;
+
+struct WgradArgs {
+    int64_t n_wt;
+    const char* saved;
+    const char* dz;
+    float* partial;
+    JobTable jobs;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// fragment (8 x 16 bit) for one 32-position tile and one 16-sample half, by two transposing reads
+__device__ __forceinline__ s16x8 tr_frag(const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 128));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int PREC>
+__device__ __forceinline__ float frag_sum(const s16x8& f) {
+    typedef typename Prec<PREC>::frag frag;
+    const frag v = __builtin_bit_cast(frag, f);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)v[j];
+    return s;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
+    typedef typename Prec<PREC>::frag frag;
+    __shared__ __attribute__((aligned(16))) char lds[WG_LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;       // 4 x 2 waves, each 2 x 4 tiles of 32 x 32
+
+    // which GEMM, which slice of the sample axis
+    int g = 0;
+    while (g + 1 < NGEMM && (int)blockIdx.x >= a.jobs.job0[g + 1]) ++g;
+    const int split = blockIdx.x - a.jobs.job0[g];
+    const int nsplit = a.jobs.splits[g];
+    const GemmDesc gd = GEMMS[g];
+    const int64_t wt0 = a.n_wt * split / nsplit, wt1 = a.n_wt * (split + 1) / nsplit;
+    const int nsteps = (int)(wt1 - wt0);
+
+    // staging: unit u of a stage (A units first, then B units) is copied by wave u % 8
+    const int n_units = gd.a_nks + gd.b_nks;
+    const int my_units = (n_units - wave + 7) >> 3;       // 0..4
+    const char* a_src = a.dz + ((size_t)dz_ks0(gd.dz_layer) * a.n_wt) * 1024 + (size_t)gd.a_ks0 * 1024;
+    const size_t a_stride = (size_t)DZ_KS[gd.dz_layer] * 1024;          // bytes per wave tile
+    const char* b_src = a.saved + ((size_t)saved_ks0(gd.b_tensor) * a.n_wt) * 1024;
+    const size_t b_stride = (size_t)gd.b_nks * 1024;
+
+    auto issue = [&](int step, int stage) {
+        const int64_t wt = wt0 + step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = wave + 8 * i;
+            if (u < n_units) {
+                const bool is_a = u < gd.a_nks;
+                const char* src = is_a ? a_src + (size_t)wt * a_stride + (size_t)u * 1024
+                                       : b_src + (size_t)wt * b_stride + (size_t)(u - gd.a_nks) * 1024;
+                char* dst = lds + stage * WG_STAGE_BYTES + (is_a ? u : 16 + (u - gd.a_nks)) * 1024;
+                __builtin_amdgcn_global_load_lds((gbl_char*)src + lane * 16, (lds_char*)dst, 16, 0, 0);
+            }
+        }
+    };
+    // wait until at most `keep_stages` stages of this wave's copies are still in flight
+    auto wait_stages = [&](int keep_stages) {
+        const int n = keep_stages * my_units;
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        }
+    };
+
+    // per-lane part of the transposing-read address (see tr_frag): 16-lane group gg, lane t4 in it
+    const int gg = lane >> 4, t4 = lane & 15;
+    const int lane_rd = (8 * (gg >> 1) + (t4 >> 2)) * 32 + (t4 & 3) * 8;
+    // unit of this lane's half of a 32-position tile, clamped to the operand (extra rows/cols are dropped later)
+    int a_unit[2], b_unit[4];
+    bool a_ok[2], b_ok[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = 2 * (2 * wr + i) + (gg & 1);
+        a_ok[i] = 2 * (2 * wr + i) < gd.a_nks;
+        a_unit[i] = (u < gd.a_nks ? u : gd.a_nks - 1) * 1024 + lane_rd;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int u = 2 * (4 * wc + j) + (gg & 1);
+        b_ok[j] = 2 * (4 * wc + j) < gd.b_nks;
+        b_unit[j] = (16 + (u < gd.b_nks ? u : gd.b_nks - 1)) * 1024 + lane_rd;
+    }
+    const bool any_ok = (a_ok[0] && b_ok[0]);
+
+    f32x16 acc[2][4];
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zero;
+    float bsum[2] = {0.f, 0.f};
+
+    if (nsteps > 0) issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    int stage = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        // stage `step` landed (this wave's share), one younger stage may stay in flight
+        wait_stages(step + 1 < nsteps ? 1 : 0);
+        __builtin_amdgcn_s_barrier();
+        if (step + 2 < nsteps) {
+            int st2 = stage + 2; if (st2 >= WG_STAGES) st2 -= WG_STAGES;
+            issue(step + 2, st2);       // its slot was last read two steps ago (all waves passed the barrier since)
+        }
+        if (any_ok) {
+            const char* base = lds + stage * WG_STAGE_BYTES;
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                s16x8 af[2], bf[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = tr_frag(base + a_unit[i] + sh * 512);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = tr_frag(base + b_unit[j] + sh * 512);
+                if (gd.has_bias && wc == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bsum[i] += frag_sum<PREC>(af[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (a_ok[i] && b_ok[j])
+                            acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]),
+                                                         acc[i][j]);
+            }
+        }
+        stage = stage + 1 == WG_STAGES ? 0 : stage + 1;
+    }
+
+    // partial block: [R][C] row-major then R bias sums
+    const int R = gd.a_nks * 16, C = gd.b_nks * 16;
+    float* out = a.partial + a.jobs.part_off[g] + (int64_t)split * gemm_out_floats(g);
+    const int col_l = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (a_ok[i] && b_ok[j]) {
+                const int col = 32 * (4 * wc + j) + col_l;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * (2 * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (row < R && col < C) out[(int64_t)row * C + col] = acc[i][j][r];
+                }
+            }
+        }
+        if (gd.has_bias && wc == 0 && a_ok[i]) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            const int row = 32 * (2 * wr + i) + (lane & 31);
+            if (hh == 0 && row < R) out[(int64_t)R * C + row] = tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. reduce + scatter to state_dict order
+// ------------------------------------------------------------------------------------------------
+// position (index inside a GEMM's row or column space) of hidden feature f
+__device__ __forceinline__ int hidden_pos(int f) {
+    const int r = f & 15;
+    return (f & ~15) + 8 * ((r >> 2) & 1) + ((r & 3) | ((r >> 3) << 2));
+}
+// position of reference encoding feature f (L frequencies)
+__device__ __forceinline__ int pe_pos(int f, int L) {
+    int q, h;
+    if (f < 3) { q = 3 * L + (f == 2); h = (f == 1); }
+    else { const int gq = f - 3; const int l = gq / 6, w = gq % 6; h = w / 3; q = 3 * l + (w % 3); }
+    return 16 * (q >> 3) + 8 * h + (q & 7);
+}
+
+struct ReduceArgs {
+    const float* partial;
+    float* d_params;
+    const float* scale;     // nullable: divide by *scale
+    JobTable jobs;
+};
+
+__device__ __forceinline__ float sum_partials(const ReduceArgs& a, int g, int idx) {
+    const float* p = a.partial + a.jobs.part_off[g] + idx;
+    const int n = a.jobs.splits[g];
+    const int stride = gemm_out_floats(g);
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += p[(int64_t)i * stride];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N_PARAMS) return;
+    int g, row, col = -1;      // col < 0: bias element
+    if (e < OFF_W1) {                                   // pts_linears.0
+        g = 0;
+        if (e < OFF_B0) { row = hidden_pos(e / 63); col = pe_pos(e % 63, 10); } else row = hidden_pos(e - OFF_B0);
+    } else if (e < OFF_W5) {                            // pts_linears.1..4
+        const int l = (e - OFF_W1) / (256 * 256 + 256), r = (e - OFF_W1) % (256 * 256 + 256);
+        g = 1 + l;
+        if (r < 65536) { row = hidden_pos(r >> 8); col = hidden_pos(r & 255); } else row = hidden_pos(r - 65536);
+    } else if (e < OFF_W6) {                            // pts_linears.5
+        if (e < OFF_B5) {
+            const int o = (e - OFF_W5) / 319, i = (e - OFF_W5) % 319;
+            row = hidden_pos(o);
+            if (i < 63) { g = 5; col = pe_pos(i, 10); } else { g = 6; col = hidden_pos(i - 63); }
+        } else { g = 6; row = hidden_pos(e - OFF_B5); }
+    } else if (e < OFF_WS) {                            // pts_linears.6..7
+        const int l = (e - OFF_W6) / (256 * 256 + 256), r = (e - OFF_W6) % (256 * 256 + 256);
+        g = 7 + l;
+        if (r < 65536) { row = hidden_pos(r >> 8); col = hidden_pos(r & 255); } else row = hidden_pos(r - 65536);
+    } else if (e < OFF_WF) {                            // sigma_linear
+        g = 10; row = 0;
+        if (e < OFF_BS) col = hidden_pos(e - OFF_WS);
+    } else if (e < OFF_WR0) {                           // feature_linear
+        g = 9;
+        const int r = e - OFF_WF;
+        if (r < 65536) { row = hidden_pos(r >> 8); col = hidden_pos(r & 255); } else row = hidden_pos(r - 65536);
+    } else if (e < OFF_WR2) {                           // rgb_layers.0
+        if (e < OFF_BR0) {
+            const int o = (e - OFF_WR0) / 283, i = (e - OFF_WR0) % 283;
+            row = hidden_pos(o);
+            if (i < 256) { g = 11; col = hidden_pos(i); } else { g = 12; col = pe_pos(i - 256, 4); }
+        } else { g = 11; row = hidden_pos(e - OFF_BR0); }
+    } else {                                            // rgb_layers.2
+        g = 13;
+        if (e < OFF_BR2) { row = (e - OFF_WR2) / 128; col = hidden_pos((e - OFF_WR2) % 128); } else row = e - OFF_BR2;
+    }
+    const int R = GEMMS[g].a_nks * 16, C = GEMMS[g].b_nks * 16;
+    const int idx = col >= 0 ? row * C + col : R * C + row;
+    float v = sum_partials(a, g, idx);
+    if (a.scale) v = v / *a.scale;
+    a.d_params[e] = v;
+}
+
+}  // namespace mlp
+}  // namespace nerf
+
+using namespace nerf::mlp;
+
+static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) {
+    const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    const int64_t n_wt = n_tiles * 8;
+    const JobTable t = make_jobs(n_wt > 0 ? n_wt : 1);
+    return round_up(n_wt * (int64_t)DZ_UNITS * 1024, 256) + round_up(partial_floats(t) * 4, 256);
+}
+
 extern "C" int nerf_mlp_bwd(int64_t M, const float* d_raw, const void* packed, int precision, const void* saved,
-                            void* workspace, int64_t workspace_bytes, float* d_params, void* stream) {
-    return NERF_E_ARCH;
+                            const float* grad_scale, void* workspace, int64_t workspace_bytes, float* d_params,
+                            void* stream) {
+    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    NERF_REQUIRE(d_params, NERF_E_NULL);
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(d_params, 0, sizeof(float) * N_PARAMS, st);
+        return e == hipSuccess ? NERF_OK : (int)e;
+    }
+    NERF_REQUIRE(d_raw && packed && saved && workspace, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(d_raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
+                     nerf_aligned(workspace, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(workspace_bytes >= nerf_mlp_bwd_workspace_bytes(M), NERF_E_WORKSPACE);
+    const int64_t n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    const int64_t n_wt = n_tiles * 8;
+    const JobTable jobs = make_jobs(n_wt);
+    char* dz = (char*)workspace;
+    float* partial = (float*)((char*)workspace + round_up(n_wt * (int64_t)DZ_UNITS * 1024, 256));
+
+    BwdArgs b{};
+    b.M = M; b.n_tiles = n_tiles; b.d_raw = d_raw; b.packed = (const char*)packed; b.saved = (const char*)saved;
+    b.dz = dz; b.scale = grad_scale;
+    const dim3 gb((unsigned)(n_tiles < 256 ? n_tiles : 256)), tb(CHAIN_THREADS);
+    if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_BF16>, gb, tb, 0, st, b);
+    else hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_FP16>, gb, tb, 0, st, b);
+    int rc = nerf_launch_status();
+    if (rc) return rc;
+
+    WgradArgs w{};
+    w.n_wt = n_wt; w.saved = (const char*)saved; w.dz = dz; w.partial = partial; w.jobs = jobs;
+    const dim3 gw((unsigned)jobs.job0[NGEMM]), tw(512);
+    if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_BF16>, gw, tw, 0, st, w);
+    else hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_FP16>, gw, tw, 0, st, w);
+    rc = nerf_launch_status();
+    if (rc) return rc;
+
+    ReduceArgs r{};
+    r.partial = partial; r.d_params = d_params; r.scale = grad_scale; r.jobs = jobs;
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, st, r);
+    return nerf_launch_status();
 }

@@ -293,9 +293,14 @@ class _FusedMLP(torch.autograd.Function):
         ws_bytes = int(lib.nerf_mlp_bwd_workspace_bytes(M))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         d_flat = torch.empty((_C.NERF_MLP_NPARAMS,), dtype=torch.float32, device=dev)
+        scale = None
+        if ctx.prec == _C.PREC["fp16"]:
+            # keep gradients inside the fp16 range: a power-of-two scale that puts max|d_raw| near 2^10
+            amax = d_raw.abs().amax().clamp_min(1e-30)
+            scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)).clamp(-24.0, 24.0)).reshape(1)
         with torch.cuda.device(dev):
-            check(lib.nerf_mlp_bwd(M, _p(d_raw), _p(ctx.packed), ctx.prec, _p(ctx.saved_acts), _p(ws), ws_bytes,
-                                   _p(d_flat), _stream(dev)), "nerf_mlp_bwd")
+            check(lib.nerf_mlp_bwd(M, _p(d_raw), _p(ctx.packed), ctx.prec, _p(ctx.saved_acts), _p(scale), _p(ws),
+                                   ws_bytes, _p(d_flat), _stream(dev)), "nerf_mlp_bwd")
         ctx.saved_acts = None
         grads = []
         off = 0
