@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the NeRF hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): one training step of scripts/train_nerf.py:288-336 with its
+intended flat ray batch -- 1024 rays per GPU, 64 coarse + 128 fine samples, stratified jitter,
+stochastic hierarchical sampling, both 8x256 networks, loss, backward, Adam.  With N > 1 every rank
+runs that step on its own rays (weak scaling) and the gradients are summed with one RCCL
+all-reduce of the flat 4.77 MB bucket before the optimizer step.  Inputs are synthetic (seeded
+Blender-style camera, random-init weights, uniform targets) and resident in HBM.
+
+Rank 0 prints one JSON line.  `value` = rays processed by all ranks / wall time (max over ranks).
+The timed steps replay the step from HIP graphs (a 1024-ray step is ~60 short launches; issued from
+Python the host would be the bottleneck).  `roofline` describes the kernel with the largest share of
+GPU time in the step; its duration comes from HIP events recorded on the launch stream around every
+launch while the same step is issued eagerly right after the timed region.  `cpu_baseline` times the CPU oracle
+(oracle/nerf_oracle.py, a restatement of the reference's PyTorch path) on the same workload on
+this host's cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MLP_FWD_FLOP = 1186816          # 2 * 593 408 MAC per sample, unpadded dims
+MLP_DGRAD_FLOP = 2 * 557696     # backward-data MACs per sample (view/point-encoding inputs need none)
+MLP_WGRAD_FLOP = 2 * 593408
+MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 peak, MI355X
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rays-per-gpu", type=int, default=1024)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying HIP graphs")
+    ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
+    return ap.parse_args()
+
+
+def build(device, precision):
+    from nerf_amd.models.nerf import NeRF, PositionalEncoder
+    from nerf_amd.optim import FlatAdam
+    from nerf_amd.utils.synthetic import seed_parameters_
+    mc = seed_parameters_(NeRF(precision=precision).to(device), 0)
+    mf = seed_parameters_(NeRF(precision=precision).to(device), 1)
+    pe, pv = PositionalEncoder(3, 10).to(device), PositionalEncoder(3, 4).to(device)
+    opt = FlatAdam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
+    return mc, mf, pe, pv, opt
+
+
+def cpu_baseline(n_rays, steps):
+    """The CPU oracle's training step (fp32 torch ops, autograd, torch.optim.Adam) on this host."""
+    from oracle import nerf_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
+    torch.set_num_threads(threads)
+    pc = {k: v.requires_grad_(True) for k, v in O.init_params(0).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.init_params(1).items()}
+    opt = torch.optim.Adam(list(pc.values()) + list(pf.values()), lr=5e-4)
+    ro, rd = O.synthetic_rays(n_rays, seed=0)
+    gen = torch.Generator().manual_seed(0)
+    tgt = torch.rand(n_rays, 3, generator=gen)
+
+    def one():
+        t1, uu, t2 = torch.rand(n_rays, 64), torch.rand(n_rays, 128), torch.rand(n_rays, 192)
+        tot, *_ = O.train_step_loss(pc, pf, ro, rd, tgt, 2.0, 6.0, 64, 128, t1, uu, t2)
+        opt.zero_grad()
+        tot.backward()
+        opt.step()
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} training steps of {n_rays} rays (64+128 samples, fwd+bwd+Adam), fp32 torch CPU, "
+                      f"{threads} threads, after 1 warm-up step"}
+
+
+def main():
+    args = parse()
+    from nerf_amd.parallel import init_distributed
+    rank, world, local_rank = init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    device = torch.device("cuda", torch.cuda.current_device())
+    import torch.distributed as dist
+    from nerf_amd import ops
+    from nerf_amd.parallel import broadcast_parameters_
+    from nerf_amd.utils.synthetic import synthetic_rays
+
+    n = args.rays_per_gpu
+    mc, mf, pe, pv, opt = build(device, args.precision)
+    broadcast_parameters_(opt.flat, world)
+    rays_o, rays_d = synthetic_rays(n, device, seed=rank)
+    target = torch.rand(n, 3, generator=torch.Generator().manual_seed(1000 + rank)).to(device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from nerf_amd.train import TrainStep
+    step_fn = TrainStep(mc, mf, pe, pv, opt, n, near=2.0, far=6.0, N_samples_coarse=64, N_samples_fine=128,
+                        world_size=world, use_graph=not args.no_graph)
+
+    def lr_at(i):      # scripts/train_nerf.py:288: lr0 * decay^(step / decay_steps)
+        return 5e-4 * (0.1 ** (i / 250000.0))
+
+    for s in range(args.warmup):
+        step_fn(rays_o, rays_d, target, lr=lr_at(s))
+    sync()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        loss = step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + s))
+    sync()
+    dt = time.perf_counter() - t0
+    # per-kernel durations: the same step issued eagerly with HIP events on the launch stream
+    step_fn.use_graph = False
+    step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + args.steps))
+    ops.KERNEL_TIMES = {}
+    for s in range(args.kernel_steps):
+        step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + args.steps + 1 + s))
+    sync()
+    times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite loss")
+
+    if rank == 0:
+        # per-kernel GPU time inside the timed region (HIP events on the launch stream)
+        ktime = {}
+        for name, evs in times.items():
+            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+            ktime[name] = (tot_ms / len(evs), len(evs), sum(u for _, _, u in evs) / len(evs), tot_ms)
+        flop = {"mlp_fwd_train": MLP_FWD_FLOP, "mlp_fwd": MLP_FWD_FLOP, "mlp_bwd_data": MLP_DGRAD_FLOP,
+                "mlp_bwd_weights": MLP_WGRAD_FLOP}
+        dom = max((k for k in ktime if k in flop), key=lambda k: ktime[k][3])
+        avg_ms, launches, units, tot_ms = ktime[dom]
+        achieved = units * flop[dom] / (avg_ms * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
+                    "samples_per_launch": units, "flop_per_sample": flop[dom],
+                    "timing": "HIP events on the launch stream around each launch, %d eager steps of the same "
+                              "training step run right after the timed region" % args.kernel_steps}
+        kernels = {}
+        for k, (a_ms, cnt, u, tot) in sorted(ktime.items()):
+            entry = {"avg_us": round(a_ms * 1e3, 2), "launches": cnt,
+                     "share_of_step": round(tot / args.kernel_steps / (dt / args.steps * 1e3), 4)}
+            if k in flop:
+                entry["TFLOP/s"] = round(u * flop[k] / (a_ms * 1e-3) / 1e12, 1)
+            elif k.startswith("composite"):
+                S = int(k.rsplit("S", 1)[1])
+                per_ray = (24 * S + 24) if "fwd" in k else (36 * S + 24)
+                entry["GB/s"] = round(u * per_ray / (a_ms * 1e-3) / 1e9, 1)
+                entry["frac_of_hbm_peak"] = round(entry["GB/s"] / HBM_PEAK_GBS, 4)
+            kernels[k] = entry
+        out = {
+            "metric": "rays/sec (64+128 samples, fwd+bwd)", "value": round(n * world * args.steps / dt, 1),
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "training step, %d rays/GPU, 64 coarse + 128 fine samples, coarse+fine 8x256 "
+                                   "NeRF, fwd+bwd+Adam (BASELINE.json configs[1])" % n,
+                       "rays_per_gpu": n, "global_rays": n * world, "samples_per_ray": "64+192 evaluations",
+                       "parallelism": "dp%d" % world if world > 1 else "single"},
+            "launch_mode": "eager" if args.no_graph else "hipgraph replay (2 graphs per step)",
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

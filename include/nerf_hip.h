@@ -166,11 +166,29 @@ int nerf_mlp_bwd(int64_t M, const float *d_raw, const void *packed, int precisio
                  const float *grad_scale, void *workspace, int64_t workspace_bytes, float *d_params,
                  void *stream);
 
+/* The two halves of nerf_mlp_bwd as separate calls (same kernels), for callers that want to
+ * time or overlap them: the backward-data chain writes every layer's dZ (16 bit,
+ * nerf_mlp_dz_bytes(M) bytes); the weight-gradient pass contracts dZ with the saved activations
+ * over the samples (workspace: nerf_mlp_partial_bytes(M) bytes of fp32 partial sums). */
+int64_t nerf_mlp_dz_bytes(int64_t n_samples);
+int64_t nerf_mlp_partial_bytes(int64_t n_samples);
+int nerf_mlp_bwd_data(int64_t M, const float *d_raw, const void *packed, int precision, const void *saved,
+                      const float *grad_scale, void *dz, void *stream);
+int nerf_mlp_bwd_weights(int64_t M, const void *saved, const void *dz, int precision, const float *grad_scale,
+                         void *partial, int64_t partial_bytes, float *d_params, void *stream);
+
 /* Adam on a flat fp32 buffer -- the optimizer.step() of scripts/train_nerf.py:336
  * (torch.optim.Adam, no weight decay, no amsgrad).  step is 1-based. */
 int nerf_adam_step(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
                    float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
                    void *stream);
+
+/* Same update with the hyper-parameters in device memory, so that the call can be captured in a
+ * HIP graph and replayed while lr changes: state = device float[8] = {lr, beta1, beta2, eps,
+ * grad_scale, step, scratch, scratch}.  The call first advances state[5] (the step count, starting
+ * from 0) and then applies the update for that step. */
+int nerf_adam_step_dev(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                       float *state, void *stream);
 
 #ifdef __cplusplus
 }

@@ -467,45 +467,66 @@ using namespace nerf::mlp;
 
 static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) {
-    const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
-    const int64_t n_wt = n_tiles * 8;
+extern "C" int64_t nerf_mlp_partial_bytes(int64_t n_samples) {
+    const int64_t n_wt = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
     const JobTable t = make_jobs(n_wt > 0 ? n_wt : 1);
-    return round_up(n_wt * (int64_t)DZ_UNITS * 1024, 256) + round_up(partial_floats(t) * 4, 256);
+    return round_up(partial_floats(t) * 4, 256);
 }
 
-extern "C" int nerf_mlp_bwd(int64_t M, const float* d_raw, const void* packed, int precision, const void* saved,
-                            const float* grad_scale, void* workspace, int64_t workspace_bytes, float* d_params,
-                            void* stream) {
+extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) {
+    const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    return round_up(n_tiles * 8 * (int64_t)DZ_UNITS * 1024, 256) + nerf_mlp_partial_bytes(n_samples);
+}
+
+static int check_bwd_common(int64_t M, int precision) {
     NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
     NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    return NERF_OK;
+}
+
+extern "C" int64_t nerf_mlp_dz_bytes(int64_t n_samples) {
+    const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    return round_up(n_tiles * 8 * (int64_t)DZ_UNITS * 1024, 256);
+}
+
+extern "C" int nerf_mlp_bwd_data(int64_t M, const float* d_raw, const void* packed, int precision,
+                                 const void* saved, const float* grad_scale, void* dz, void* stream) {
+    int rc = check_bwd_common(M, precision);
+    if (rc) return rc;
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE(d_raw && packed && saved && dz, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(d_raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
+                     nerf_aligned(dz, 256), NERF_E_ALIGN);
+    const int64_t n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    BwdArgs b{};
+    b.M = M; b.n_tiles = n_tiles; b.d_raw = d_raw; b.packed = (const char*)packed; b.saved = (const char*)saved;
+    b.dz = (char*)dz; b.scale = grad_scale;
+    const dim3 gb((unsigned)(n_tiles < 256 ? n_tiles : 256)), tb(CHAIN_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_BF16>, gb, tb, 0, st, b);
+    else hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_FP16>, gb, tb, 0, st, b);
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* saved, const void* dz, int precision,
+                                    const float* grad_scale, void* partial, int64_t partial_bytes, float* d_params,
+                                    void* stream) {
+    int rc = check_bwd_common(M, precision);
+    if (rc) return rc;
     NERF_REQUIRE(d_params, NERF_E_NULL);
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) {
         hipError_t e = hipMemsetAsync(d_params, 0, sizeof(float) * N_PARAMS, st);
         return e == hipSuccess ? NERF_OK : (int)e;
     }
-    NERF_REQUIRE(d_raw && packed && saved && workspace, NERF_E_NULL);
-    NERF_REQUIRE(nerf_aligned(d_raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
-                     nerf_aligned(workspace, 256), NERF_E_ALIGN);
-    NERF_REQUIRE(workspace_bytes >= nerf_mlp_bwd_workspace_bytes(M), NERF_E_WORKSPACE);
-    const int64_t n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
-    const int64_t n_wt = n_tiles * 8;
+    NERF_REQUIRE(saved && dz && partial, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(saved, 256) && nerf_aligned(dz, 256) && nerf_aligned(partial, 256), NERF_E_ALIGN);
+    const int64_t n_wt = (M + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
     const JobTable jobs = make_jobs(n_wt);
-    char* dz = (char*)workspace;
-    float* partial = (float*)((char*)workspace + round_up(n_wt * (int64_t)DZ_UNITS * 1024, 256));
-
-    BwdArgs b{};
-    b.M = M; b.n_tiles = n_tiles; b.d_raw = d_raw; b.packed = (const char*)packed; b.saved = (const char*)saved;
-    b.dz = dz; b.scale = grad_scale;
-    const dim3 gb((unsigned)(n_tiles < 256 ? n_tiles : 256)), tb(CHAIN_THREADS);
-    if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_BF16>, gb, tb, 0, st, b);
-    else hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_FP16>, gb, tb, 0, st, b);
-    int rc = nerf_launch_status();
-    if (rc) return rc;
+    NERF_REQUIRE(partial_bytes >= partial_floats(jobs) * 4, NERF_E_WORKSPACE);
 
     WgradArgs w{};
-    w.n_wt = n_wt; w.saved = (const char*)saved; w.dz = dz; w.partial = partial; w.jobs = jobs;
+    w.n_wt = n_wt; w.saved = (const char*)saved; w.dz = (const char*)dz; w.partial = (float*)partial; w.jobs = jobs;
     const dim3 gw((unsigned)jobs.job0[NGEMM]), tw(512);
     if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_BF16>, gw, tw, 0, st, w);
     else hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_FP16>, gw, tw, 0, st, w);
@@ -513,7 +534,25 @@ extern "C" int nerf_mlp_bwd(int64_t M, const float* d_raw, const void* packed, i
     if (rc) return rc;
 
     ReduceArgs r{};
-    r.partial = partial; r.d_params = d_params; r.scale = grad_scale; r.jobs = jobs;
+    r.partial = (const float*)partial; r.d_params = d_params; r.scale = grad_scale; r.jobs = jobs;
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, st, r);
     return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_bwd(int64_t M, const float* d_raw, const void* packed, int precision, const void* saved,
+                            const float* grad_scale, void* workspace, int64_t workspace_bytes, float* d_params,
+                            void* stream) {
+    int rc = check_bwd_common(M, precision);
+    if (rc) return rc;
+    NERF_REQUIRE(d_params, NERF_E_NULL);
+    if (M > 0) {
+        NERF_REQUIRE(workspace, NERF_E_NULL);
+        NERF_REQUIRE(nerf_aligned(workspace, 256), NERF_E_ALIGN);
+        NERF_REQUIRE(workspace_bytes >= nerf_mlp_bwd_workspace_bytes(M), NERF_E_WORKSPACE);
+    }
+    const int64_t dzb = nerf_mlp_dz_bytes(M);
+    rc = nerf_mlp_bwd_data(M, d_raw, packed, precision, saved, grad_scale, workspace, stream);
+    if (rc) return rc;
+    return nerf_mlp_bwd_weights(M, saved, workspace, precision, grad_scale, (char*)workspace + dzb,
+                                workspace_bytes - dzb, d_params, stream);
 }

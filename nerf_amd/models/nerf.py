@@ -99,11 +99,15 @@ class NeRF(nn.Module):
         return list(self.parameters())
 
     def packed_weights(self) -> torch.Tensor:
-        """MFMA fragment streams of the current weights; re-packed whenever a parameter changed."""
+        """MFMA fragment streams of the current weights.  While gradients are being recorded the
+        weights are packed on every call (one small kernel; it also keeps the call sequence identical
+        from step to step, which HIP-graph capture of a training step relies on); under no_grad the
+        packed buffer is cached and re-made only when a parameter was modified or replaced."""
         self._require_supported()
         ps = self.ordered_params()
-        key = (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
-        if key != self._pack_key:
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        key = None if training else (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
+        if training or key != self._pack_key:
             with torch.no_grad():
                 flat = torch.cat([p.detach().reshape(-1) for p in ps])
                 self._packed = ops.mlp_pack(flat, self.precision)

@@ -36,6 +36,28 @@ def _stream(dev: torch.device):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# Optional per-kernel timing with events on the launch stream (used by bench.py for the roofline
+# figure).  KERNEL_TIMES maps a kernel name to a list of (start_event, end_event, units).
+KERNEL_TIMES = None
+
+
+class _timed:
+    def __init__(self, name, dev, units):
+        self.name, self.dev, self.units = name, dev, units
+
+    def __enter__(self):
+        if KERNEL_TIMES is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.dev))
+
+    def __exit__(self, *exc):
+        if KERNEL_TIMES is not None:
+            self.e1.record(torch.cuda.current_stream(self.dev))
+            KERNEL_TIMES.setdefault(self.name, []).append((self.e0, self.e1, self.units))
+        return False
+
+
 # ---------------------------------------------------------------------------
 # rays / sample placement / positional encoding
 # ---------------------------------------------------------------------------
@@ -127,7 +149,7 @@ class _Composite(torch.autograd.Function):
         acc = torch.empty((N,), dtype=torch.float32, device=dev)
         weights = torch.empty((N, S), dtype=torch.float32, device=dev)
         alpha = torch.empty((N, S), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed(f"composite_fwd_S{S}", dev, N):
             check(lib.nerf_composite_fwd(N, S, _p(raw), _p(z), int(bool(white_bkgd)), _p(rgb), _p(depth),
                                          _p(disp), _p(acc), _p(weights), _p(alpha), _stream(dev)),
                   "nerf_composite_fwd")
@@ -146,7 +168,7 @@ class _Composite(torch.autograd.Function):
         g_rgb, g_depth, g_disp, g_acc = prep(g_rgb, "g_rgb"), prep(g_depth, "g_depth"), prep(g_disp, "g_disp"), prep(g_acc, "g_acc")
         g_w, g_alpha = prep(g_w, "g_weights"), prep(g_alpha, "g_alpha")
         d_raw = torch.empty_like(raw)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed(f"composite_bwd_S{S}", dev, N):
             check(lib.nerf_composite_bwd(N, S, _p(raw), _p(z), int(ctx.white), _p(g_rgb), _p(g_depth), _p(g_disp),
                                          _p(g_acc), _p(g_w), _p(g_alpha), _p(d_raw), _stream(dev)),
                   "nerf_composite_bwd")
@@ -271,8 +293,9 @@ class _FusedMLP(torch.autograd.Function):
         prec = _C.PREC[precision]
         with torch.cuda.device(dev):
             if mode == "rays":
-                check(lib.nerf_mlp_fwd(N, S, _p(rays_o), _p(rays_d), _p(z), _p(packed), prec, _p(raw), _p(saved),
-                                       _stream(dev)), "nerf_mlp_fwd")
+                with _timed("mlp_fwd_train" if need_grad else "mlp_fwd", dev, M):
+                    check(lib.nerf_mlp_fwd(N, S, _p(rays_o), _p(rays_d), _p(z), _p(packed), prec, _p(raw), _p(saved),
+                                           _stream(dev)), "nerf_mlp_fwd")
             else:
                 check(lib.nerf_mlp_fwd_encoded(M, _p(x_pts), _p(x_views), _p(packed), prec, _p(raw), _p(saved),
                                                _stream(dev)), "nerf_mlp_fwd_encoded")
@@ -290,8 +313,9 @@ class _FusedMLP(torch.autograd.Function):
         d_raw = _gpu_f32(d_raw, "d_raw")
         dev = d_raw.device
         M = ctx.M
-        ws_bytes = int(lib.nerf_mlp_bwd_workspace_bytes(M))
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        dz = torch.empty((int(lib.nerf_mlp_dz_bytes(M)),), dtype=torch.uint8, device=dev)
+        part_bytes = int(lib.nerf_mlp_partial_bytes(M))
+        part = torch.empty((part_bytes,), dtype=torch.uint8, device=dev)
         d_flat = torch.empty((_C.NERF_MLP_NPARAMS,), dtype=torch.float32, device=dev)
         scale = None
         if ctx.prec == _C.PREC["fp16"]:
@@ -299,8 +323,13 @@ class _FusedMLP(torch.autograd.Function):
             amax = d_raw.abs().amax().clamp_min(1e-30)
             scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)).clamp(-24.0, 24.0)).reshape(1)
         with torch.cuda.device(dev):
-            check(lib.nerf_mlp_bwd(M, _p(d_raw), _p(ctx.packed), ctx.prec, _p(ctx.saved_acts), _p(scale), _p(ws),
-                                   ws_bytes, _p(d_flat), _stream(dev)), "nerf_mlp_bwd")
+            st = _stream(dev)
+            with _timed("mlp_bwd_data", dev, M):
+                check(lib.nerf_mlp_bwd_data(M, _p(d_raw), _p(ctx.packed), ctx.prec, _p(ctx.saved_acts), _p(scale),
+                                            _p(dz), st), "nerf_mlp_bwd_data")
+            with _timed("mlp_bwd_weights", dev, M):
+                check(lib.nerf_mlp_bwd_weights(M, _p(ctx.saved_acts), _p(dz), ctx.prec, _p(scale), _p(part),
+                                               part_bytes, _p(d_flat), st), "nerf_mlp_bwd_weights")
         ctx.saved_acts = None
         grads = []
         off = 0
@@ -339,3 +368,18 @@ def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, 
         check(lib.nerf_adam_step(n, _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), float(lr), float(beta1),
                                  float(beta2), float(eps), int(step), float(grad_scale), _stream(params.device)),
               "nerf_adam_step")
+
+
+def adam_step_dev(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                  state: torch.Tensor) -> None:
+    """Adam with hyper-parameters in the device tensor ``state`` = [lr, beta1, beta2, eps, grad_scale, step, -, -]."""
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),
+                  (state, "state")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"{nm} must be a contiguous fp32 GPU tensor")
+    n = params.numel()
+    if not (grads.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n and state.numel() >= 8):
+        raise ValueError("adam_step_dev: size mismatch")
+    with torch.cuda.device(params.device):
+        check(lib.nerf_adam_step_dev(n, _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(state),
+                                     _stream(params.device)), "nerf_adam_step_dev")

@@ -1,0 +1,92 @@
+"""The training step of scripts/train_nerf.py:288-336 as one callable, optionally replayed from a HIP graph.
+
+A 1024-ray step is about sixty short kernel launches; issued one by one from Python the host is
+the bottleneck.  ``TrainStep`` runs the same call sequence eagerly or captures it once into two HIP
+graphs (forward + backward + gradient bucket; optimizer) and replays them, with the inputs in
+static buffers and the optimizer's hyper-parameters in device memory so that the learning rate can
+change between replays.  Between the two graphs sits the only collective of data-parallel
+training, one summing all-reduce of the flat gradient bucket.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .models.nerf import render_hierarchical
+from .optim import FlatAdam
+from .parallel import allreduce_gradients_
+
+
+class TrainStep:
+    def __init__(self, model_coarse, model_fine, embed_fn_pts, embed_fn_views, optimizer: FlatAdam, n_rays: int,
+                 near: float = 2.0, far: float = 6.0, N_samples_coarse: int = 64, N_samples_fine: int = 128,
+                 lindisp: bool = False, white_bkgd: bool = False, world_size: int = 1, use_graph: bool = True):
+        self.mc, self.mf, self.pe, self.pv, self.opt = model_coarse, model_fine, embed_fn_pts, embed_fn_views, optimizer
+        self.near, self.far, self.nc, self.nf = near, far, N_samples_coarse, N_samples_fine
+        self.lindisp, self.white = lindisp, white_bkgd
+        self.world = world_size
+        self.use_graph = use_graph
+        dev = optimizer.flat.device
+        self.rays_o = torch.zeros((n_rays, 3), device=dev)
+        self.rays_d = torch.zeros((n_rays, 3), device=dev)
+        self.target = torch.zeros((n_rays, 3), device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self.loss_coarse = torch.zeros((), device=dev)
+        self.loss_fine = torch.zeros((), device=dev)
+        self._g_fb: Optional[torch.cuda.CUDAGraph] = None
+        self._g_opt: Optional[torch.cuda.CUDAGraph] = None
+        self.opt.device_state()[4] = 1.0 / world_size        # gradients are summed over ranks, then averaged
+
+    # the step body: losses of train_nerf.py:299, :330-331; gradients into the optimizer's flat bucket
+    def _forward_backward(self):
+        coarse, fine = render_hierarchical(self.mc, self.mf, self.pe, self.pv, self.rays_o, self.rays_d, self.near,
+                                           self.far, self.nc, self.nf, rand=True, det=False, lindisp=self.lindisp,
+                                           white_bkgd=self.white)
+        lc = torch.mean((coarse["rgb_map"] - self.target) ** 2)
+        lf = torch.mean((fine["rgb_map"] - self.target) ** 2)
+        total = lc + lf
+        self.opt.zero_grad(set_to_none=True)
+        total.backward()
+        self.opt.gather_grads()
+        self.loss_coarse.copy_(lc.detach()); self.loss_fine.copy_(lf.detach()); self.loss.copy_(total.detach())
+
+    def _optimizer(self):
+        self.opt.step_dev(grads_gathered=True)
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up off the capture stream, as graph capture requires;
+            for _ in range(2):                 # the optimizer is not stepped here
+                self._forward_backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self._forward_backward()
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt):
+            self._optimizer()
+        # capture only records: nothing ran, so neither the weights nor the step counter moved
+
+    def __call__(self, rays_o: torch.Tensor, rays_d: torch.Tensor, target_rgb: torch.Tensor,
+                 lr: Optional[float] = None) -> torch.Tensor:
+        """One optimisation step on this rank's rays; returns the (device) total loss of this rank."""
+        self.rays_o.copy_(rays_o, non_blocking=True)
+        self.rays_d.copy_(rays_d, non_blocking=True)
+        self.target.copy_(target_rgb, non_blocking=True)
+        if lr is not None:
+            self.opt.param_groups[0]["lr"] = lr
+            self.opt.device_state()[0:1].fill_(lr)
+        if self.use_graph:
+            if self._g_fb is None:
+                self._capture()
+            self._g_fb.replay()
+            allreduce_gradients_(self.opt.flat_grad, self.world)
+            self._g_opt.replay()
+        else:
+            self._forward_backward()
+            allreduce_gradients_(self.opt.flat_grad, self.world)
+            self._optimizer()
+        return self.loss
