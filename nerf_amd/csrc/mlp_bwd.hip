@@ -50,7 +50,7 @@ constexpr int gemm_out_off(int g) { int o = 0; for (int i = 0; i < g; ++i) o += 
 constexpr int gemm_stage_kb(int g) { return GEMMS[g].a_nks + GEMMS[g].b_nks; }
 constexpr int TOTAL_STAGE_KB = [] { int s = 0; for (int g = 0; g < NGEMM; ++g) s += gemm_stage_kb(g); return s; }();
 
-constexpr int WGRAD_TARGET_JOBS = 512;     // about two workgroups' worth of jobs per CU
+constexpr int WGRAD_TARGET_JOBS = 256;     // one workgroup's worth of jobs per CU
 
 struct JobTable {
     int splits[NGEMM];       // sample-axis splits of each GEMM
@@ -207,8 +207,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
 // ------------------------------------------------------------------------------------------------
 // 2. weight-gradient GEMMs
 // ------------------------------------------------------------------------------------------------
-constexpr int WG_STAGES = 3;
+constexpr int WG_STAGES = 4;                  // one being read, up to three in flight
 constexpr int WG_STAGE_BYTES = 32 * 1024;     // up to 16 A units + 16 B units
+#ifndef NERF_WG_DMA_AUX
+#define NERF_WG_DMA_AUX 0
+#endif
+constexpr int WG_DMA_AUX = NERF_WG_DMA_AUX;    // cache policy bits of the streaming copies (2 = nt)
 constexpr int WG_LDS_BYTES = WG_STAGES * WG_STAGE_BYTES;
 
 struct WgradArgs {
@@ -222,13 +226,53 @@ struct WgradArgs {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-// fragment (8 x 16 bit) for one 32-position tile and one 16-sample half, by two transposing reads
-__device__ __forceinline__ s16x8 tr_frag(const char* p) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 128));
+// Transposing LDS read as inline asm.  The compiler cannot see which LDS bytes an LDS-DMA wrote, so
+// in front of a builtin LDS read it waits for EVERY outstanding DMA (vmcnt(0)), which would
+// serialise the staging pipeline; the asm form leaves the wait to the counted vmcnt + barrier of the
+// stage protocol.  Results are valid after tr_wait() on the same registers.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(uint32_t addr) {
+    s16x4 r;
+#ifdef NERF_WG_NO_LDSREAD
+    r[0] = (short)addr; r[1] = (short)(addr >> 3); r[2] = (short)OFF; r[3] = 1;
+    asm volatile("" : "+v"(r));
+    return r;
+#endif
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+struct TrFrag { s16x4 lo, hi; };
+// fragment (8 x 16 bit) for one 32-position tile and one 16-sample half: samples 4r..4r+3 of the
+// lane's 8 come from read r
+template <int OFF>
+__device__ __forceinline__ TrFrag tr_frag(uint32_t addr) {
+    TrFrag f;
+    f.lo = tr_read<OFF>(addr);
+    f.hi = tr_read<OFF + 128>(addr);
+    return f;
+}
+// wait until at most N LDS operations of this wave are outstanding, and tie the wait to the
+// fragments so that the compiler cannot move their uses above it
+template <int N>
+__device__ __forceinline__ void tr_wait2(TrFrag& a, TrFrag& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait1(TrFrag& a) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.lo), "+v"(a.hi) : "n"(N) : "memory");
+}
+template <int TI, int TJ, int N>
+__device__ __forceinline__ void tr_wait_all(TrFrag (&ta)[TI], TrFrag (&tb)[TJ]) {
+    static_assert(N <= 15, "lgkmcnt is a 4-bit counter");
+#pragma unroll
+    for (int i = 0; i < TI; ++i) tr_wait1<N>(ta[i]);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) tr_wait1<N>(tb[j]);
+}
+__device__ __forceinline__ s16x8 tr_join(const TrFrag& f) {
     s16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    r[0] = f.lo[0]; r[1] = f.lo[1]; r[2] = f.lo[2]; r[3] = f.lo[3];
+    r[4] = f.hi[0]; r[5] = f.hi[1]; r[6] = f.hi[2]; r[7] = f.hi[3];
     return r;
 }
 
@@ -242,145 +286,179 @@ __device__ __forceinline__ float frag_sum(const s16x8& f) {
     return s;
 }
 
-template <int PREC>
-__global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
+// One GEMM shape: A_NKS row units x B_NKS column units, computed by a WR x WC grid of waves, each
+// owning TI x TJ tiles of 32 x 32.  Everything about the shape is a compile-time constant so that the
+// per-step body is straight-line code.
+template <int PREC, int A_NKS, int B_NKS, int WR, int WC, int TI, int TJ>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char* lds) {
     typedef typename Prec<PREC>::frag frag;
-    __shared__ __attribute__((aligned(16))) char lds[WG_LDS_BYTES];
-
+    static_assert(WR * WC <= 8 && WR * TI * 2 >= A_NKS && WC * TJ * 2 == B_NKS, "wave grid must cover the block");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;       // 4 x 2 waves, each 2 x 4 tiles of 32 x 32
+    const int wr = wave / WC, wc = wave % WC;
+    const bool active = wave < WR * WC;
+    const GemmDesc gd = GEMMS[g];
 
-    // which GEMM, which slice of the sample axis
-    int g = 0;
-    while (g + 1 < NGEMM && (int)blockIdx.x >= a.jobs.job0[g + 1]) ++g;
     const int split = blockIdx.x - a.jobs.job0[g];
     const int nsplit = a.jobs.splits[g];
-    const GemmDesc gd = GEMMS[g];
     const int64_t wt0 = a.n_wt * split / nsplit, wt1 = a.n_wt * (split + 1) / nsplit;
     const int nsteps = (int)(wt1 - wt0);
 
     // staging: unit u of a stage (A units first, then B units) is copied by wave u % 8
-    const int n_units = gd.a_nks + gd.b_nks;
-    const int my_units = (n_units - wave + 7) >> 3;       // 0..4
+    constexpr int N_UNITS = A_NKS + B_NKS;
+    const int my_units = (N_UNITS - wave + 7) >> 3;       // 0..4
     const char* a_src = a.dz + ((size_t)dz_ks0(gd.dz_layer) * a.n_wt) * 1024 + (size_t)gd.a_ks0 * 1024;
     const size_t a_stride = (size_t)DZ_KS[gd.dz_layer] * 1024;          // bytes per wave tile
     const char* b_src = a.saved + ((size_t)saved_ks0(gd.b_tensor) * a.n_wt) * 1024;
-    const size_t b_stride = (size_t)gd.b_nks * 1024;
+    constexpr size_t b_stride = (size_t)B_NKS * 1024;
 
     auto issue = [&](int step, int stage) {
         const int64_t wt = wt0 + step;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int u = wave + 8 * i;
-            if (u < n_units) {
-                const bool is_a = u < gd.a_nks;
+            if (u < N_UNITS) {
+                const bool is_a = u < A_NKS;
                 const char* src = is_a ? a_src + (size_t)wt * a_stride + (size_t)u * 1024
-                                       : b_src + (size_t)wt * b_stride + (size_t)(u - gd.a_nks) * 1024;
-                char* dst = lds + stage * WG_STAGE_BYTES + (is_a ? u : 16 + (u - gd.a_nks)) * 1024;
-                __builtin_amdgcn_global_load_lds((gbl_char*)src + lane * 16, (lds_char*)dst, 16, 0, 0);
+                                       : b_src + (size_t)wt * b_stride + (size_t)(u - A_NKS) * 1024;
+                char* dst = lds + stage * WG_STAGE_BYTES + (is_a ? u : 16 + (u - A_NKS)) * 1024;
+                __builtin_amdgcn_global_load_lds((gbl_char*)src + lane * 16, (lds_char*)dst, 16, 0, WG_DMA_AUX);
             }
         }
     };
     // wait until at most `keep_stages` stages of this wave's copies are still in flight
     auto wait_stages = [&](int keep_stages) {
         const int n = keep_stages * my_units;
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        }
+        if (n == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
 
+    const uint32_t lds_base = (uint32_t)(uintptr_t)((lds_char*)lds);   // LDS byte address of the staging area
     // per-lane part of the transposing-read address (see tr_frag): 16-lane group gg, lane t4 in it
     const int gg = lane >> 4, t4 = lane & 15;
-    const int lane_rd = (8 * (gg >> 1) + (t4 >> 2)) * 32 + (t4 & 3) * 8;
-    // unit of this lane's half of a 32-position tile, clamped to the operand (extra rows/cols are dropped later)
-    int a_unit[2], b_unit[4];
-    bool a_ok[2], b_ok[4];
+    const uint32_t lane_rd = (8 * (gg >> 1) + (t4 >> 2)) * 32 + (t4 & 3) * 8;
+    // unit of this lane's half of a 32-position tile, clamped to the operand (extra rows are dropped later)
+    uint32_t a_unit[TI], b_unit[TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = 2 * (2 * wr + i) + (gg & 1);
-        a_ok[i] = 2 * (2 * wr + i) < gd.a_nks;
-        a_unit[i] = (u < gd.a_nks ? u : gd.a_nks - 1) * 1024 + lane_rd;
+    for (int i = 0; i < TI; ++i) {
+        const int u = 2 * (TI * wr + i) + (gg & 1);
+        a_unit[i] = lds_base + (u < A_NKS ? u : A_NKS - 1) * 1024 + lane_rd;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int u = 2 * (4 * wc + j) + (gg & 1);
-        b_ok[j] = 2 * (4 * wc + j) < gd.b_nks;
-        b_unit[j] = (16 + (u < gd.b_nks ? u : gd.b_nks - 1)) * 1024 + lane_rd;
+    for (int j = 0; j < TJ; ++j) {
+        const int u = 2 * (TJ * wc + j) + (gg & 1);
+        b_unit[j] = lds_base + (16 + u) * 1024 + lane_rd;
     }
-    const bool any_ok = (a_ok[0] && b_ok[0]);
 
-    f32x16 acc[2][4];
+    f32x16 acc[TI][TJ];
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = zero;
-    float bsum[2] = {0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = zero;
+    float bsum[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
+    const bool do_bias = gd.has_bias && wc == 0;
 
     if (nsteps > 0) issue(0, 0);
     if (nsteps > 1) issue(1, 1);
+    if (nsteps > 2) issue(2, 2);
     int stage = 0;
     for (int step = 0; step < nsteps; ++step) {
-        // stage `step` landed (this wave's share), one younger stage may stay in flight
-        wait_stages(step + 1 < nsteps ? 1 : 0);
+        // stage `step` landed (this wave's share); up to two younger stages may stay in flight
+        const int younger = nsteps - 1 - step;
+        wait_stages(younger < 2 ? younger : 2);
         __builtin_amdgcn_s_barrier();
-        if (step + 2 < nsteps) {
-            int st2 = stage + 2; if (st2 >= WG_STAGES) st2 -= WG_STAGES;
-            issue(step + 2, st2);       // its slot was last read two steps ago (all waves passed the barrier since)
+        if (step + 3 < nsteps) {
+            int st3 = stage + 3; if (st3 >= WG_STAGES) st3 -= WG_STAGES;
+            issue(step + 3, st3);       // its slot was read in the previous step (all waves passed the barrier since)
         }
-        if (any_ok) {
-            const char* base = lds + stage * WG_STAGE_BYTES;
+        if (active) {
+            const uint32_t sb = stage * WG_STAGE_BYTES;
+            TrFrag ta0[TI], tb0[TJ], ta1[TI], tb1[TJ];     // the two 16-sample halves of the stage
 #pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                s16x8 af[2], bf[4];
+            for (int i = 0; i < TI; ++i) ta0[i] = tr_frag<0>(sb + a_unit[i]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = tr_frag(base + a_unit[i] + sh * 512);
+            for (int j = 0; j < TJ; ++j) tb0[j] = tr_frag<0>(sb + b_unit[j]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = tr_frag(base + b_unit[j] + sh * 512);
-                if (gd.has_bias && wc == 0) {
+            for (int i = 0; i < TI; ++i) ta1[i] = tr_frag<512>(sb + a_unit[i]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) bsum[i] += frag_sum<PREC>(af[i]);
-                }
+            for (int j = 0; j < TJ; ++j) tb1[j] = tr_frag<512>(sb + b_unit[j]);
+            tr_wait_all<TI, TJ, 0>(ta0, tb0);      // one LDS round trip per stage: both halves were requested above
+            s16x8 af[TI], bf[TJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i) af[i] = tr_join(ta0[i]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (a_ok[i] && b_ok[j])
-                            acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]),
-                                                         acc[i][j]);
+            for (int j = 0; j < TJ; ++j) bf[j] = tr_join(tb0[j]);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) bsum[i] += frag_sum<PREC>(af[i]);
             }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
+            tr_wait_all<TI, TJ, 0>(ta1, tb1);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = tr_join(ta1[i]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = tr_join(tb1[j]);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) bsum[i] += frag_sum<PREC>(af[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
         }
         stage = stage + 1 == WG_STAGES ? 0 : stage + 1;
     }
 
     // partial block: [R][C] row-major then R bias sums
-    const int R = gd.a_nks * 16, C = gd.b_nks * 16;
+    if (!active) return;
+    constexpr int R = A_NKS * 16, C = B_NKS * 16;
     float* out = a.partial + a.jobs.part_off[g] + (int64_t)split * gemm_out_floats(g);
     const int col_l = lane & 31, hh = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (a_ok[i] && b_ok[j]) {
-                const int col = 32 * (4 * wc + j) + col_l;
+        for (int j = 0; j < TJ; ++j) {
+            const int col = 32 * (TJ * wc + j) + col_l;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * (2 * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (row < R && col < C) out[(int64_t)row * C + col] = acc[i][j][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (TI * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < R) out[(int64_t)row * C + col] = acc[i][j][r];
             }
         }
-        if (gd.has_bias && wc == 0 && a_ok[i]) {
+        if (do_bias) {
             const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-            const int row = 32 * (2 * wr + i) + (lane & 31);
+            const int row = 32 * (TI * wr + i) + (lane & 31);
             if (hh == 0 && row < R) out[(int64_t)R * C + row] = tot;
         }
     }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[WG_LDS_BYTES];
+    int g = 0;
+    while (g + 1 < NGEMM && (int)blockIdx.x >= a.jobs.job0[g + 1]) ++g;
+    // shape dispatch (workgroup-uniform): <A units, B units, wave grid, tiles per wave>
+    if (g == 0 || g == 5) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, g, lds);
+    else if (g == 10) wgrad_body<PREC, 1, 16, 1, 8, 1, 1>(a, g, lds);
+    else if (g == 11) wgrad_body<PREC, 8, 16, 4, 2, 1, 4>(a, g, lds);
+    else if (g == 12) wgrad_body<PREC, 8, 2, 4, 1, 1, 1>(a, g, lds);
+    else if (g == 13) wgrad_body<PREC, 1, 8, 1, 4, 1, 1>(a, g, lds);
+    else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, g, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
