@@ -1,0 +1,46 @@
+"""Frame rendering: the chunk loop of scripts/render_nerf.py:260-314, sharded over ranks by image rows."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .models.nerf import render_hierarchical, render_rays
+from .parallel import gather_rows, shard_rows
+from .utils.ray_utils import get_rays
+
+
+@torch.no_grad()
+def render_image(model_coarse, model_fine, embed_fn_pts, embed_fn_views, H: int, W: int, focal: float,
+                 c2w: torch.Tensor, near: float = 2.0, far: float = 6.0, N_samples_coarse: int = 64,
+                 N_samples_fine: int = 128, chunk: int = 65536, lindisp: bool = False, white_bkgd: bool = False,
+                 rank: int = 0, world_size: int = 1, gather: bool = True) -> torch.Tensor:
+    """Deterministic two-pass render of one camera (rand=False, det=True, as render_nerf.py:275-303).
+
+    Each rank generates and renders only its block of image rows; with ``gather`` the blocks are
+    all-gathered into the full [H, W, 3] frame on every rank, otherwise this rank's
+    [nrows, W, 3] block is returned.  ``chunk`` is the number of rays per launch group (the
+    reference's eval_batch_size, render_nerf.py:55; the kernels prefer larger chunks than 4096).
+    ``model_fine=None`` renders the coarse pass only (render_nerf.py:282-285)."""
+    row0, nrows = shard_rows(H, rank, world_size)
+    rays_o, rays_d = get_rays(H, W, focal, c2w, row0=row0, nrows=nrows)
+    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    out = torch.empty((nrows * W, 3), dtype=torch.float32, device=rays_o.device)
+    for s in range(0, nrows * W, chunk):
+        ro, rd = rays_o[s:s + chunk], rays_d[s:s + chunk]
+        if model_fine is None:
+            res = render_rays(model_coarse, embed_fn_pts, embed_fn_views, ro, rd, near, far, N_samples_coarse,
+                              rand=False, lindisp=lindisp, white_bkgd=white_bkgd)
+        else:
+            _, res = render_hierarchical(model_coarse, model_fine, embed_fn_pts, embed_fn_views, ro, rd, near, far,
+                                         N_samples_coarse, N_samples_fine, rand=False, det=True, lindisp=lindisp,
+                                         white_bkgd=white_bkgd)
+        out[s:s + chunk] = res["rgb_map"]
+    block = out.reshape(nrows, W, 3)
+    return gather_rows(block, H, rank, world_size) if gather else block
+
+
+def to_uint8(img: torch.Tensor) -> torch.Tensor:
+    """clip to [0,1] then the truncating float -> uint8 cast of the reference
+    (render_nerf.py:309 + utils/image_utils.py:52-92), on the device, so that only bytes cross PCIe."""
+    return (img.clamp(0.0, 1.0) * 255.0).to(torch.uint8)
