@@ -35,6 +35,7 @@ MLP_DGRAD_FLOP = 2 * 557696     # backward-data MACs per sample (view/point-enco
 MLP_WGRAD_FLOP = 2 * 593408
 MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 peak, MI355X
 HBM_PEAK_GBS = 8000.0
+WGRAD_BYTES_PER_SAMPLE = 312 * 1024 // 32   # saved activations (158 KiB) + dZ (154 KiB) per 32 samples
 
 
 def parse():
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-render", action="store_true", help="skip the 800x800 frame render measurement")
+    ap.add_argument("--render-chunk", type=int, default=65536)
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying HIP graphs")
     ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
     return ap.parse_args()
@@ -60,6 +63,48 @@ def build(device, precision):
     pe, pv = PositionalEncoder(3, 10).to(device), PositionalEncoder(3, 4).to(device)
     opt = FlatAdam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
     return mc, mf, pe, pv, opt
+
+
+def render_section(mc, mf, pe, pv, device, args):
+    """BASELINE.json configs[2]: one 800x800 frame (640 000 rays, 64 + 128 samples, deterministic, no_grad),
+    rays generated on the GPU, rendered in chunks.  Reports rays/s and the achieved rates of the MLP
+    forward (MFMA) and of the compositing / ray-generation kernels (HBM)."""
+    from nerf_amd import ops
+    from nerf_amd.render import render_image
+    from nerf_amd.utils.synthetic import focal_from_fov, pose_spherical
+    H = W = 800
+    c2w = pose_spherical(0.0, -30.0, 4.0).to(device)
+    focal = focal_from_fov(W)
+    render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=args.render_chunk)          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 2
+    for _ in range(frames):
+        render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=args.render_chunk)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / frames
+    ops.KERNEL_TIMES = {}
+    render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=args.render_chunk)
+    torch.cuda.synchronize()
+    times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+    sec = {"workload": "800x800 frame, 640000 rays, 64+128 samples, chunk %d, no_grad, deterministic" % args.render_chunk,
+           "s_per_frame": round(dt, 4), "rays_per_s": round(H * W / dt, 1), "kernels": {}}
+    for name, evs in sorted(times.items()):
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        units = sum(u for _, _, u in evs)
+        e = {"total_ms": round(tot_ms, 3), "launches": len(evs)}
+        if name == "mlp_fwd":
+            e["TFLOP/s"] = round(units * MLP_FWD_FLOP / (tot_ms * 1e-3) / 1e12, 1)
+            e["frac_of_mfma_peak"] = round(e["TFLOP/s"] / MFMA_PEAK_TFLOPS, 4)
+        elif name.startswith("composite_fwd"):
+            S = int(name.rsplit("S", 1)[1])
+            e["GB/s"] = round(units * (28 * S + 24) / (tot_ms * 1e-3) / 1e9, 1)     # alpha is written too: +4S
+            e["frac_of_hbm_peak"] = round(e["GB/s"] / HBM_PEAK_GBS, 4)
+        elif name == "get_rays":
+            e["GB/s"] = round(units * 24 / (tot_ms * 1e-3) / 1e9, 1)
+            e["frac_of_hbm_peak"] = round(e["GB/s"] / HBM_PEAK_GBS, 4)
+        sec["kernels"][name] = e
+    return sec
 
 
 def cpu_baseline(n_rays, steps):
@@ -158,11 +203,19 @@ def main():
                 "mlp_bwd_weights": MLP_WGRAD_FLOP}
         dom = max((k for k in ktime if k in flop), key=lambda k: ktime[k][3])
         avg_ms, launches, units, tot_ms = ktime[dom]
-        achieved = units * flop[dom] / (avg_ms * 1e-3) / 1e12
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        if dom == "mlp_bwd_weights":
+            # the weight-gradient pass contracts over samples: every saved-activation unit and every dZ
+            # unit is read once, 312 KiB per 32 samples; it is HBM-bound in this design
+            achieved = units * WGRAD_BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9
+            rl = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_sample": WGRAD_BYTES_PER_SAMPLE}
+        else:
+            achieved = units * flop[dom] / (avg_ms * 1e-3) / 1e12
+            rl = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flop[dom]}
+        roofline = {"kernel": dom, **rl, "traffic": None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
-                    "samples_per_launch": units, "flop_per_sample": flop[dom],
+                    "samples_per_launch": units,
                     "timing": "HIP events on the launch stream around each launch, %d eager steps of the same "
                               "training step run right after the timed region" % args.kernel_steps}
         kernels = {}
@@ -171,6 +224,10 @@ def main():
                      "share_of_step": round(tot / args.kernel_steps / (dt / args.steps * 1e3), 4)}
             if k in flop:
                 entry["TFLOP/s"] = round(u * flop[k] / (a_ms * 1e-3) / 1e12, 1)
+                entry["frac_of_mfma_peak"] = round(entry["TFLOP/s"] / MFMA_PEAK_TFLOPS, 4)
+                if k == "mlp_bwd_weights":
+                    entry["GB/s"] = round(u * WGRAD_BYTES_PER_SAMPLE / (a_ms * 1e-3) / 1e9, 1)
+                    entry["frac_of_hbm_peak"] = round(entry["GB/s"] / HBM_PEAK_GBS, 4)
             elif k.startswith("composite"):
                 S = int(k.rsplit("S", 1)[1])
                 per_ray = (24 * S + 24) if "fwd" in k else (36 * S + 24)
@@ -189,6 +246,8 @@ def main():
             "launch_mode": "eager" if args.no_graph else "hipgraph replay (2 graphs per step)",
             "roofline": roofline, "kernels": kernels,
         }
+        if world == 1 and not args.no_render:
+            out["render"] = render_section(mc, mf, pe, pv, device, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_steps)
         print(json.dumps(out), flush=True)

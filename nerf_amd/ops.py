@@ -72,7 +72,7 @@ def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor, row0: int = 0,
     nrows = H - row0 if nrows is None else int(nrows)
     ro = torch.empty((nrows, W, 3), dtype=torch.float32, device=c2w.device)
     rd = torch.empty((nrows, W, 3), dtype=torch.float32, device=c2w.device)
-    with torch.cuda.device(c2w.device):
+    with torch.cuda.device(c2w.device), _timed("get_rays", c2w.device, nrows * W):
         check(lib.nerf_get_rays(H, W, float(focal), _p(c2w), 4, int(row0), nrows, _p(ro), _p(rd),
                                 _stream(c2w.device)), "nerf_get_rays")
     return ro, rd

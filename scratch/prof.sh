@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 passes over a short bench run; outputs under gpurun_out/prof_r1/
+set -e
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof_r1; mkdir -p $O
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --kernel-steps 2"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/trace_bench.json 2> $O/trace.err
+echo "trace done"
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- $B > $O/pmc_mfma_bench.json 2> $O/pmc_mfma.err
+echo "pmc mfma done"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err
+echo "pmc fetch done"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write_bench.json 2> $O/pmc_write.err
+echo "pmc write done"
+find $O -name "*.csv" | head -20
+du -sh $O
