@@ -101,49 +101,77 @@ __device__ __forceinline__ void store_unit_frag(char* base, int ks0, int nks, in
     *reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
 }
 
-// accumulator tile (gradient w.r.t. a post-ReLU activation) -> masked 16-bit fragments
-template <int PREC, bool MASK>
-__device__ __forceinline__ void grad_to_frags(const f32x16& acc, const typename Prec<PREC>::frag& h0,
-                                              const typename Prec<PREC>::frag& h1, typename Prec<PREC>::frag& f0,
+// accumulator tile (gradient w.r.t. a post-ReLU activation) -> 16-bit fragments, zeroed where the
+// activation was not positive.  `signs` is this lane's mask dword of the tile pair, PAR the tile's
+// parity in the pair (see mask_bit).
+template <int PREC, bool MASK, int PAR>
+__device__ __forceinline__ void grad_to_frags(const f32x16& acc, uint32_t signs, typename Prec<PREC>::frag& f0,
                                               typename Prec<PREC>::frag& f1) {
     typedef typename Prec<PREC>::elem T;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float a = (!MASK || (float)h0[j] > 0.0f) ? acc[j] : 0.0f;
-        const float b = (!MASK || (float)h1[j] > 0.0f) ? acc[8 + j] : 0.0f;
+        float a = acc[j], b = acc[8 + j];
+        if (MASK) {   // bit -> 0 / all ones, then and
+            a = __int_as_float(__float_as_int(a) & __builtin_amdgcn_sbfe((int)signs, mask_bit(PAR, j), 1));
+            b = __int_as_float(__float_as_int(b) & __builtin_amdgcn_sbfe((int)signs, mask_bit(PAR, 8 + j), 1));
+        }
         f0[j] = (T)a;
         f1[j] = (T)b;
     }
 }
 
+// Sign masks travel global -> LDS by DMA, one KiB per wave and tensor, into three per-wave buffers
+// behind the ring: two alternate between consecutive hidden layers, the third holds the masks of G
+// for the next pass.  Each wave reads only what it copied itself, so no barrier is involved; the
+// copy is issued a whole layer (>= 2 chunk entries) before its first read, and mask_landed() before
+// that read waits until at most the 8 newest VMEM operations of the wave are outstanding - which
+// are the newest chunk of ring DMA and the dZ stores of the last two tiles, never the mask copy.
+constexpr int MASK_LDS_OFF = CHAIN_LDS_BYTES;
+constexpr int MASK_BUF_BYTES = 8 * 1024;
+constexpr int DGRAD_LDS_BYTES = CHAIN_LDS_BYTES + 3 * MASK_BUF_BYTES;
+enum { MB_A = 0, MB_B = 1, MB_G = 2 };
+
+__device__ __forceinline__ void mask_issue(const char* masks, int64_t wt, int tensor, char* lds, int buf, int wave,
+                                           int lane) {
+    gbl_char* g = (gbl_char*)(masks + ((size_t)wt * MASK_TENSORS + tensor) * 1024) + lane * 16;
+    lds_char* l = (lds_char*)(lds + MASK_LDS_OFF + buf * MASK_BUF_BYTES + wave * 1024);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+}
+__device__ __forceinline__ void mask_landed() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+
 template <int PREC>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdArgs a) {
     typedef typename Prec<PREC>::frag frag;
     typedef typename Prec<PREC>::elem T;
-    __shared__ __attribute__((aligned(16))) char lds[CHAIN_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[DGRAD_LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int lane_off = c * 32 + h * 16;
     const float gscale = a.scale ? *a.scale : 1.0f;
+    const int64_t n_wt = a.n_tiles * 8;
+    const char* const masks = a.saved + (size_t)n_wt * SAVED_UNITS * 1024;
+    const char* const mask_rd = lds + MASK_LDS_OFF + wave * 1024 + lane * 4;
 
+    // masks of G for the first pass go first: the ring's 8 initial copies are younger
+    if ((int64_t)blockIdx.x < a.n_tiles) mask_issue(masks, (int64_t)blockIdx.x * 8 + wave, MASK_G, lds, MB_G, wave, lane);
     Ring ring;
     ring_init(ring, lds, a.packed + PACK_BWD_OFF, BWD_CHUNKS, lane, wave);
-    const int64_t n_wt = a.n_tiles * 8;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t wt = tile * 8 + wave;
         const int64_t m = wt * WAVE_SAMPLES + c;
         const bool valid = m < a.M;
+        mask_issue(masks, wt, 7, lds, MB_A, wave, lane);
 
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid && h == 0) dr = reinterpret_cast<const float4*>(a.d_raw)[m];
         dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale;
 
         frag da[H_KS + 1], db[H_KS];
-        frag mk[2][2];
+        uint32_t mk[2];
 
         // dZ10: slots 0..2 = d rgb_raw (lane half 0, elements 0..2)
 #pragma unroll
@@ -153,30 +181,33 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
 
         // generic masked step: acc tile mt of d(activation saved as tensor SV) -> out[2mt], out[2mt+1],
         // stored as dZ of layer DZL
-        auto mask_pre = [&](auto SV, int nks) {
-            return [&, nks](int mt) {
-                constexpr int sv = decltype(SV)::value;
-                mk[mt & 1][0] = load_unit_frag<PREC>(a.saved, saved_ks0(sv), nks, n_wt, wt, 2 * mt, lane_off);
-                mk[mt & 1][1] = load_unit_frag<PREC>(a.saved, saved_ks0(sv), nks, n_wt, wt, 2 * mt + 1, lane_off);
+        // tile mt of a masked layer: its mask dword is read from LDS buffer BUF one tile early (with
+        // the accumulator init) and applied when the tile is finished
+        auto mask_pre = [&](auto BUF) {
+            return [&](int mt) {
+                constexpr int buf = decltype(BUF)::value;
+                mk[mt & 1] = *reinterpret_cast<const uint32_t*>(mask_rd + buf * MASK_BUF_BYTES + (mt >> 1) * 256);
                 return zero;
             };
         };
         auto mask_epi = [&](auto DZL, frag* out) {
             return [&, out](int mt, const f32x16& acc) {
                 constexpr int dzl = decltype(DZL)::value;
-                grad_to_frags<PREC, true>(acc, mk[mt & 1][0], mk[mt & 1][1], out[2 * mt], out[2 * mt + 1]);
+                if (mt & 1) grad_to_frags<PREC, true, 1>(acc, mk[1], out[2 * mt], out[2 * mt + 1]);
+                else grad_to_frags<PREC, true, 0>(acc, mk[0], out[2 * mt], out[2 * mt + 1]);
                 store_unit_frag<PREC>(a.dz, dz_ks0(dzl), DZ_KS[dzl], n_wt, wt, 2 * mt, lane_off, out[2 * mt]);
                 store_unit_frag<PREC>(a.dz, dz_ks0(dzl), DZ_KS[dzl], n_wt, wt, 2 * mt + 1, lane_off, out[2 * mt + 1]);
             };
         };
 #define NERF_IC(N) std::integral_constant<int, N>()
         // d0: dG = W_r2^T dZ10, masked by G > 0  -> dZ9 (8 k-steps) in da
-        run_layer<PREC, bwd_block0(0), 4, 1, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_G), G_KS), mask_epi(NERF_IC(9), da));
+        mask_landed();
+        run_layer<PREC, bwd_block0(0), 4, 1, 0, 2>(ring, lds, db, db, mask_pre(NERF_IC(MB_G)), mask_epi(NERF_IC(9), da));
         // d1: dF = W_r0[:, :256]^T dZ9 (feature_linear has no activation) -> dZ8[0..255] in db; sigma joins as k-step 16
-        run_layer<PREC, bwd_block0(1), 8, G_KS, 0>(ring, lds, da, da, [&](int) { return zero; },
+        run_layer<PREC, bwd_block0(1), 8, G_KS, 0, 2>(ring, lds, da, da, [&](int) { return zero; },
                                                   [&](int mt, const f32x16& acc) {
             frag f0 = {}, f1 = {};
-            grad_to_frags<PREC, false>(acc, f0, f0, f0, f1);
+            grad_to_frags<PREC, false, 0>(acc, 0u, f0, f1);
             db[2 * mt] = f0; db[2 * mt + 1] = f1;
             store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, 2 * mt, lane_off, f0);
             store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, 2 * mt + 1, lane_off, f1);
@@ -186,17 +217,25 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
         for (int j = 0; j < 8; ++j) dsig[j] = (T)0.0f;
         dsig[0] = (T)dr.w;                                   // slot 256 = sigma_raw (lane half 0, element 0)
         store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, H_KS, lane_off, dsig);
-        // d2: dH7 = [W_f; w_sigma]^T dZ8, masked by H7 > 0 -> dZ7 in da
-        run_layer<PREC, bwd_block0(2), 8, H_KS, 1>(ring, lds, db, &dsig, mask_pre(NERF_IC(SV_H0 + 7), H_KS),
-                                                  mask_epi(NERF_IC(7), da));
-        // d3..d9: hidden layers 7, 6, 5 (H rows), 4, 3, 2, 1
-        run_layer<PREC, bwd_block0(3), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 6), H_KS), mask_epi(NERF_IC(6), db));
-        run_layer<PREC, bwd_block0(4), 8, H_KS, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_H0 + 5), H_KS), mask_epi(NERF_IC(5), da));
-        run_layer<PREC, bwd_block0(5), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 4), H_KS), mask_epi(NERF_IC(4), db));
-        run_layer<PREC, bwd_block0(6), 8, H_KS, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_H0 + 3), H_KS), mask_epi(NERF_IC(3), da));
-        run_layer<PREC, bwd_block0(7), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 2), H_KS), mask_epi(NERF_IC(2), db));
-        run_layer<PREC, bwd_block0(8), 8, H_KS, 0>(ring, lds, db, db, mask_pre(NERF_IC(SV_H0 + 1), H_KS), mask_epi(NERF_IC(1), da));
-        run_layer<PREC, bwd_block0(9), 8, H_KS, 0>(ring, lds, da, da, mask_pre(NERF_IC(SV_H0 + 0), H_KS), mask_epi(NERF_IC(0), db));
+        // d2: dH7 = [W_f; w_sigma]^T dZ8, masked by H7 > 0 -> dZ7 in da.  Before each masked layer: its
+        // masks have landed; the next layer's start their way into the other buffer.
+#define NERF_MASKED(D, NK1, IN, IN1, BUF, NEXT_TENSOR, NEXT_BUF, DZL, OUT)                                   \
+        mask_landed();                                                                                       \
+        mask_issue(masks, wt, NEXT_TENSOR, lds, NEXT_BUF, wave, lane);                                       \
+        run_layer<PREC, bwd_block0(D), 8, H_KS, NK1, 2>(ring, lds, IN, IN1, mask_pre(NERF_IC(BUF)), mask_epi(NERF_IC(DZL), OUT));
+        NERF_MASKED(2, 1, db, &dsig, MB_A, 6, MB_B, 7, da)
+        // d3..d8: hidden layers 6, 5 (H rows), 4, 3, 2, 1
+        NERF_MASKED(3, 0, da, da, MB_B, 5, MB_A, 6, db)
+        NERF_MASKED(4, 0, db, db, MB_A, 4, MB_B, 5, da)
+        NERF_MASKED(5, 0, da, da, MB_B, 3, MB_A, 4, db)
+        NERF_MASKED(6, 0, db, db, MB_A, 2, MB_B, 3, da)
+        NERF_MASKED(7, 0, da, da, MB_B, 1, MB_A, 2, db)
+        NERF_MASKED(8, 0, db, db, MB_A, 0, MB_B, 1, da)
+        // d9: hidden layer 0; the copy started here is the next pass's G mask
+        mask_landed();
+        if (tile + gridDim.x < a.n_tiles) mask_issue(masks, (tile + gridDim.x) * 8 + wave, MASK_G, lds, MB_G, wave, lane);
+        run_layer<PREC, bwd_block0(9), 8, H_KS, 0, 2>(ring, lds, da, da, mask_pre(NERF_IC(MB_B)), mask_epi(NERF_IC(0), db));
+#undef NERF_MASKED
 #undef NERF_IC
         // The stream is padded to whole chunks; the pad blocks of the last chunk are never read, and
         // the next pass enters a fresh chunk at its block 0.

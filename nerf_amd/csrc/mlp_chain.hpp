@@ -64,8 +64,12 @@ __device__ __forceinline__ void ring_init(Ring& r, char* lds, const void* stream
 //    share of the chunk about to be read is in LDS;
 //  - the barrier extends that to every wave's share, and also says every wave has finished
 //    reading the previous chunk, whose slot is the one refilled next.
+//  - YOUNGER: a lower bound on the VMEM operations (stores of saved tensors) this wave issued after
+//    its newest chunk of DMA; they complete after it, so they may stay in flight as well.
+template <int YOUNGER = 0>
 __device__ __forceinline__ void ring_enter(Ring& r, char* lds) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK) : "memory");
+    static_assert(DMA_PER_CHUNK + YOUNGER <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK + YOUNGER) : "memory");
     __builtin_amdgcn_s_barrier();
     r.slot = r.slot == RING_SLOTS - 1 ? 0 : r.slot + 1;
     int refill = r.slot + 2;
@@ -110,7 +114,15 @@ constexpr int pf_lo(int B0, int NB, int i) {
     return pf_hi(B0, NB, i - 1) + 1;
 }
 
-template <int PREC, int B0, int NT, int NK0, int NK1, class Init, class Epi>
+// tile epilogues of this layer that ran during the CHUNK_BLOCKS blocks before block i
+constexpr int tiles_ended_before(int NK, int i) {
+    int n = 0;
+    for (int j = (i > CHUNK_BLOCKS ? i - CHUNK_BLOCKS : 0); j < i; ++j) n += (j % NK == NK - 1);
+    return n;
+}
+
+// VM_PER_TILE: VMEM operations every tile epilogue of this layer is known to issue (0 if unknown).
+template <int PREC, int B0, int NT, int NK0, int NK1, int VM_PER_TILE = 0, class Init, class Epi>
 __device__ __forceinline__ void run_layer(Ring& ring, char* lds, const typename Prec<PREC>::frag* in0,
                                           const typename Prec<PREC>::frag* in1, Init&& init, Epi&& epi) {
     typedef typename Prec<PREC>::frag frag;
@@ -122,7 +134,14 @@ __device__ __forceinline__ void run_layer(Ring& ring, char* lds, const typename 
     for (int i = 0; i < NB; ++i) {
         const int m = i / NK, ks = i % NK;
         const int b = B0 + i;
-        if (b % CHUNK_BLOCKS == 0) ring_enter(ring, lds);
+        if (b % CHUNK_BLOCKS == 0) {
+            // folds to one call once the loop is unrolled
+            const int younger = VM_PER_TILE * tiles_ended_before(NK, i);
+            if (younger >= 8) ring_enter<8>(ring, lds);
+            else if (younger >= 4) ring_enter<4>(ring, lds);
+            else if (younger >= 2) ring_enter<2>(ring, lds);
+            else ring_enter<0>(ring, lds);
+        }
         const int lo = pf_lo(B0, NB, i), hi = pf_hi(B0, NB, i);
 #pragma unroll
         for (int d = 0; d <= PF; ++d) {

@@ -148,6 +148,18 @@ constexpr int DZ_KS[NLAYERS] = {16, 16, 16, 16, 16, 16, 16, 16, 17, 8, 1};
 constexpr int dz_ks0(int l) { int k = 0; for (int i = 0; i < l; ++i) k += DZ_KS[i]; return k; }
 constexpr int DZ_UNITS = dz_ks0(NLAYERS);       // 154 KiB per 32 samples
 
+// ---- ReLU sign masks -----------------------------------------------------------------------------
+// The backward-data chain needs only the sign of each post-ReLU activation.  Behind the saved units
+// the forward pass therefore keeps, per wave tile, MASK_TENSORS KiB of bit masks: tensor t (H0..H7 =
+// 0..7, G = 8) of wave tile wt is the KiB at index wt * MASK_TENSORS + t.  Inside it the dword at
+// byte 256*p + 4*lane holds, for that lane, the signs of output tiles 2p and 2p+1: accumulator
+// element r of tile 2p+par is bit mask_bit(par, r).  (The bit order is what falls out of reducing
+// the packed 16-bit pairs two at a time.)
+constexpr int MASK_TENSORS = 9;
+constexpr int MASK_G = 8;
+constexpr int mask_bit(int par, int r) { return 8 * par + 16 * (r & 1) + (r >> 1); }
+constexpr int64_t saved_bytes_per_wave_tile() { return (int64_t)(SAVED_UNITS + MASK_TENSORS) * 1024; }
+
 // ---- operand types -------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

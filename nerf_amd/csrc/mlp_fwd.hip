@@ -89,6 +89,21 @@ __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t
     *reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
 }
 
+// signs of one finished output tile (already ReLU'd and rounded: 16-bit values with a clear top bit),
+// in the bits 8-15 / 24-31 pattern described at mask_bit().  x + 0x7fff carries into bit 15 exactly
+// when the 16-bit value x is non-zero.
+template <int PREC>
+__device__ __forceinline__ uint32_t sign_bits(const typename Prec<PREC>::frag& f0, const typename Prec<PREC>::frag& f1) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 a = __builtin_bit_cast(u32x4, f0), b = __builtin_bit_cast(u32x4, f1);
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m = (m >> 1) | ((a[q] + 0x7fff7fffu) & 0x80008000u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m = (m >> 1) | ((b[q] + 0x7fff7fffu) & 0x80008000u);
+    return m;
+}
+
 template <int PREC, bool SAVE, bool ENCODED>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs a) {
     typedef typename Prec<PREC>::frag frag;
@@ -109,6 +124,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
     Ring ring;
     ring_init(ring, lds, a.packed + PACK_FWD_OFF, FWD_CHUNKS, lane, wave);
     const int64_t n_wt = a.n_tiles * 8;
+    char* const mask_base = SAVE ? a.saved + (size_t)n_wt * SAVED_UNITS * 1024 : nullptr;
 
     for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t wt = tile * 8 + wave;
@@ -140,7 +156,15 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
                 save_frag<PREC>(a.saved, saved_ks0(SV_PE), PE_KS, n_wt, wt, ks, lane_off, pe[ks]);
         }
 
+        constexpr int SV = SAVE ? 2 : 0;     // stores per tile epilogue
         frag ha[H_KS], hb[H_KS];
+        uint32_t even_bits = 0;               // sign bits of the last even tile, until its odd partner ends
+        char* const mask_wt = SAVE ? mask_base + (size_t)wt * MASK_TENSORS * 1024 + lane * 4 : nullptr;
+        auto save_signs = [&](int tensor, int mt, const frag& f0, const frag& f1) {
+            const uint32_t bits = sign_bits<PREC>(f0, f1);
+            if (mt & 1) *reinterpret_cast<uint32_t*>(mask_wt + tensor * 1024 + (mt >> 1) * 256) = (even_bits >> 8) | bits;
+            else even_bits = bits;
+        };
         auto hidden = [&](auto LAYER, frag* out) {
             return [&, out](int mt, const f32x16& acc) {
                 constexpr int layer = decltype(LAYER)::value;
@@ -149,23 +173,24 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
                     save_frag<PREC>(a.saved, saved_ks0(SV_H0 + layer), H_KS, n_wt, wt, 2 * mt, lane_off, out[2 * mt]);
                     save_frag<PREC>(a.saved, saved_ks0(SV_H0 + layer), H_KS, n_wt, wt, 2 * mt + 1, lane_off,
                                     out[2 * mt + 1]);
+                    save_signs(layer, mt, out[2 * mt], out[2 * mt + 1]);
                 }
             };
         };
 #define NERF_BIAS(LAYER) [&](int mt) { return bias_tile(bias_lds, LAYER, mt, h); }
 #define NERF_IC(N) std::integral_constant<int, N>()
-        run_layer<PREC, fwd_block0(0), 8, PE_KS, 0>(ring, lds, pe, pe, NERF_BIAS(0), hidden(NERF_IC(0), ha));
-        run_layer<PREC, fwd_block0(1), 8, H_KS, 0>(ring, lds, ha, ha, NERF_BIAS(1), hidden(NERF_IC(1), hb));
-        run_layer<PREC, fwd_block0(2), 8, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(2), hidden(NERF_IC(2), ha));
-        run_layer<PREC, fwd_block0(3), 8, H_KS, 0>(ring, lds, ha, ha, NERF_BIAS(3), hidden(NERF_IC(3), hb));
-        run_layer<PREC, fwd_block0(4), 8, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(4), hidden(NERF_IC(4), ha));
-        run_layer<PREC, fwd_block0(5), 8, PE_KS, H_KS>(ring, lds, pe, ha, NERF_BIAS(5), hidden(NERF_IC(5), hb));
-        run_layer<PREC, fwd_block0(6), 8, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(6), hidden(NERF_IC(6), ha));
-        run_layer<PREC, fwd_block0(7), 8, H_KS, 0>(ring, lds, ha, ha, NERF_BIAS(7), hidden(NERF_IC(7), hb));
+        run_layer<PREC, fwd_block0(0), 8, PE_KS, 0, SV>(ring, lds, pe, pe, NERF_BIAS(0), hidden(NERF_IC(0), ha));
+        run_layer<PREC, fwd_block0(1), 8, H_KS, 0, SV>(ring, lds, ha, ha, NERF_BIAS(1), hidden(NERF_IC(1), hb));
+        run_layer<PREC, fwd_block0(2), 8, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(2), hidden(NERF_IC(2), ha));
+        run_layer<PREC, fwd_block0(3), 8, H_KS, 0, SV>(ring, lds, ha, ha, NERF_BIAS(3), hidden(NERF_IC(3), hb));
+        run_layer<PREC, fwd_block0(4), 8, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(4), hidden(NERF_IC(4), ha));
+        run_layer<PREC, fwd_block0(5), 8, PE_KS, H_KS, SV>(ring, lds, pe, ha, NERF_BIAS(5), hidden(NERF_IC(5), hb));
+        run_layer<PREC, fwd_block0(6), 8, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(6), hidden(NERF_IC(6), ha));
+        run_layer<PREC, fwd_block0(7), 8, H_KS, 0, SV>(ring, lds, ha, ha, NERF_BIAS(7), hidden(NERF_IC(7), hb));
 
         // L8: feature_linear (no activation) -> ha, sigma_linear -> row 0 of tile 8
         float sigma = 0.f;
-        run_layer<PREC, fwd_block0(8), 9, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(8), [&](int mt, const f32x16& acc) {
+        run_layer<PREC, fwd_block0(8), 9, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(8), [&](int mt, const f32x16& acc) {
             if (mt < 8) {
                 tile_to_frags<PREC, false>(acc, ha[2 * mt], ha[2 * mt + 1]);
                 if (SAVE) {
@@ -186,11 +211,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
             for (int ks = 0; ks < VPE_KS; ++ks)
                 save_frag<PREC>(a.saved, saved_ks0(SV_VPE), VPE_KS, n_wt, wt, ks, lane_off, vpe[ks]);
         }
-        run_layer<PREC, fwd_block0(9), 4, H_KS, VPE_KS>(ring, lds, ha, vpe, NERF_BIAS(9), [&](int mt, const f32x16& acc) {
+        run_layer<PREC, fwd_block0(9), 4, H_KS, VPE_KS, SV>(ring, lds, ha, vpe, NERF_BIAS(9), [&](int mt, const f32x16& acc) {
             tile_to_frags<PREC, true>(acc, hb[2 * mt], hb[2 * mt + 1]);
             if (SAVE) {
                 save_frag<PREC>(a.saved, saved_ks0(SV_G), G_KS, n_wt, wt, 2 * mt, lane_off, hb[2 * mt]);
                 save_frag<PREC>(a.saved, saved_ks0(SV_G), G_KS, n_wt, wt, 2 * mt + 1, lane_off, hb[2 * mt + 1]);
+                save_signs(MASK_G, mt, hb[2 * mt], hb[2 * mt + 1]);
             }
         });
 
@@ -213,7 +239,7 @@ using namespace nerf::mlp;
 
 extern "C" int64_t nerf_mlp_saved_bytes(int64_t n_samples) {
     const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
-    return n_tiles * 8 * (int64_t)SAVED_UNITS * 1024;
+    return n_tiles * 8 * saved_bytes_per_wave_tile();
 }
 
 static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* stream) {
