@@ -18,7 +18,8 @@ import torch.nn as nn
 
 from .. import ops
 
-_PRECISIONS = ("bf16", "fp16")
+_PRECISIONS = ("bf16", "fp16", "fp32")
+_FUSED_PRECISIONS = ("bf16", "fp16")
 
 
 class PositionalEncoder(nn.Module):
@@ -58,6 +59,9 @@ class NeRF(nn.Module):
     ``NotImplementedError`` when run.
 
     ``precision`` selects the MFMA operand type ('bf16' or 'fp16'); accumulation is fp32.
+    ``precision='fp32'`` is the validation mode: the layers run one by one as fp32 library GEMMs
+    (rocBLAS through ``torch.nn.functional.linear``) under plain autograd, for every architecture
+    the constructor accepts; the encodings and compositing around it are still the HIP kernels.
     """
 
     def __init__(self, D: int = 8, W: int = 256, input_ch_pts: int = 63, input_ch_views: int = 27,
@@ -85,14 +89,20 @@ class NeRF(nn.Module):
         return (self.D == 8 and self.W == 256 and self.input_ch_pts == 63 and self.input_ch_views == 27
                 and list(self.skips) == [4] and self.use_viewdirs)
 
+    def fused(self) -> bool:
+        """True when calls go to the fused 16-bit MFMA kernels."""
+        if self.precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {_PRECISIONS}, got {self.precision!r}")
+        return self.precision in _FUSED_PRECISIONS
+
     def _require_supported(self):
         if not self.kernel_supported():
             raise NotImplementedError(
                 "the HIP MLP kernels implement D=8, W=256, input_ch_pts=63, input_ch_views=27, skips=[4], "
                 f"use_viewdirs=True; got D={self.D}, W={self.W}, pts={self.input_ch_pts}, "
                 f"views={self.input_ch_views}, skips={list(self.skips)}, use_viewdirs={self.use_viewdirs}")
-        if self.precision not in _PRECISIONS:
-            raise ValueError(f"precision must be one of {_PRECISIONS}, got {self.precision!r}")
+        if self.precision not in _FUSED_PRECISIONS:
+            raise ValueError(f"the fused kernels take precision 'bf16' or 'fp16', got {self.precision!r}")
 
     def ordered_params(self) -> List[torch.Tensor]:
         """Parameters in state_dict order (the order of the flat buffer the kernels index)."""
@@ -116,12 +126,16 @@ class NeRF(nn.Module):
 
     def forward_rays(self, rays_o: torch.Tensor, rays_d: torch.Tensor, z_vals: torch.Tensor) -> torch.Tensor:
         """Fused sample placement on the ray, both encodings and the MLP: raw [N_rays, S, 4]."""
+        if not self.fused():
+            raise NotImplementedError("forward_rays is the fused 16-bit path; in fp32 mode call render_rays or forward")
         return ops.fused_mlp_rays(rays_o, rays_d, z_vals, self.precision, self.packed_weights(),
                                   self.ordered_params())
 
     def forward(self, x_pts_encoded: torch.Tensor, x_views_encoded: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.use_viewdirs and x_views_encoded is None:
             raise ValueError("View directions (x_views_encoded) must be provided when use_viewdirs is True.")
+        if not self.fused():
+            return self._forward_fp32(x_pts_encoded, x_views_encoded)
         self._require_supported()
         if x_pts_encoded.shape[-1] != 63 or x_views_encoded.shape[-1] != 27:
             raise ValueError("expected encoded inputs of width 63 and 27")
@@ -131,6 +145,20 @@ class NeRF(nn.Module):
             raise NotImplementedError("gradients with respect to the encoded inputs are not implemented")
         return ops.fused_mlp_encoded(x_pts_encoded, x_views_encoded, self.precision, self.packed_weights(),
                                      self.ordered_params())
+
+
+    def _forward_fp32(self, x_pts_encoded: torch.Tensor, x_views_encoded: Optional[torch.Tensor]) -> torch.Tensor:
+        """Layer-by-layer fp32 evaluation of nerf.py:173-209 (validation mode, any architecture)."""
+        h = x_pts_encoded
+        for i, layer in enumerate(self.pts_linears):
+            h = torch.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat((x_pts_encoded, h), dim=-1)
+        if not self.use_viewdirs:
+            return self.output_linear(h)
+        sigma = self.sigma_linear(h)
+        rgb = self.rgb_layers(torch.cat((self.feature_linear(h), x_views_encoded), dim=-1))
+        return torch.cat((rgb, sigma), dim=-1)
 
 
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, N_samples: int, det: bool = False, *,
@@ -167,7 +195,7 @@ def render_rays(nerf_model, embed_fn_pts, embed_fn_views, rays_o: torch.Tensor, 
     else:
         z_vals = ops.place_samples(n_rays, near, far, N_samples, lindisp, dev, z_vals_override, t_rand)
 
-    fused = (isinstance(nerf_model, NeRF) and nerf_model.kernel_supported() and use_viewdirs
+    fused = (isinstance(nerf_model, NeRF) and nerf_model.fused() and nerf_model.kernel_supported() and use_viewdirs
              and isinstance(embed_fn_pts, PositionalEncoder) and embed_fn_pts.is_standard(10)
              and isinstance(embed_fn_views, PositionalEncoder) and embed_fn_views.is_standard(4))
     if fused:
