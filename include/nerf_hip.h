@@ -55,6 +55,21 @@ int nerf_get_rays(int H, int W, float focal, const float *c2w, int c2w_ld, int r
                   float *rays_o, float *rays_d, void *stream);
 
 /* ------------------------------------------------------------------------
+ * ray batch from an image bank -- datasets/blender.py:92-103 (x/255, alpha blend onto
+ * black or white) and :146-161 (get_rays per image), evaluated per ray instead of per
+ * image.  pix [n]: global pixel ids  image*H*W + y*W + x  (the caller guarantees
+ * 0 <= pix < n_images*H*W).  poses: per image at least 12 floats (top 3x4 of the pose,
+ * row-major), pose_stride floats apart (16 for [n,4,4]).  images: uint8
+ * [n_images, H, W, channels], channels 3 or 4.  lut: 256 floats, lut[v] = v/255 as the
+ * loader rounds it.  target may be NULL (rays only); then images and lut are not read.
+ * Outputs rays_o, rays_d, target: [n, 3].
+ */
+int nerf_gather_rays(int64_t n, const int64_t *pix, int n_images, int H, int W, float focal,
+                     const float *poses, int pose_stride, const uint8_t *images, int channels,
+                     const float *lut, int white_bkgd, float *rays_o, float *rays_d, float *target,
+                     void *stream);
+
+/* ------------------------------------------------------------------------
  * stand-alone positional encoding -- models/nerf.py:68-76.
  * x [n, d] -> out [n, d*(1+2L)] = [x, sin(f0 x), cos(f0 x), ...]; freqs: L floats
  * (the module's freq_bands buffer).

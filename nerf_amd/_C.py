@@ -26,6 +26,7 @@ _SIGS = {
     "nerf_version": (c_int, []),
     "nerf_error_string": (c_char_p, [c_int]),
     "nerf_get_rays": (c_int, [c_int, c_int, c_float, P, c_int, c_int, c_int, P, P, P]),
+    "nerf_gather_rays": (c_int, [c_int64, P, c_int, c_int, c_int, c_float, P, c_int, P, c_int, P, c_int, P, P, P, P]),
     "nerf_posenc": (c_int, [c_int64, c_int, c_int, P, P, P, P]),
     "nerf_place_samples": (c_int, [c_int64, c_int, c_float, c_float, P, P, c_int, P, P, P, P]),
     "nerf_composite_fwd": (c_int, [c_int64, c_int, P, P, c_int, P, P, P, P, P, P, P]),

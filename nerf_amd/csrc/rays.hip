@@ -1,6 +1,7 @@
 // Ray generation and sample placement: bandwidth-bound, write-mostly kernels.
 //   nerf_get_rays      <- src/nerf_project/utils/ray_utils.py:38-65
 //   nerf_place_samples <- src/nerf_project/models/nerf.py:373-402
+//   nerf_gather_rays   <- src/nerf_project/datasets/blender.py:92-103, :146-161 (per ray instead of per image)
 // Compiled with -ffp-contract=off: the reference evaluates these formulas as
 // separate fp32 multiplies and adds.
 #include "common.hpp"
@@ -47,6 +48,45 @@ __global__ __launch_bounds__(256) void get_rays_kernel(int H, int W, float focal
         } else {
             const int rem = (int)(npix - p0) * 3;
             for (int i = 0; i < rem; ++i) { rd[3 * p0 + i] = d[i]; ro[3 * p0 + i] = o[i]; }
+        }
+    }
+}
+
+// One training ray per thread: pixel `pix` of the image bank -> its ray (same arithmetic as
+// get_rays_kernel for that pixel and that image's pose) and its target colour (8-bit channels through
+// the 256-entry table `lut` = x/255 as the loader computes it, then the loader's alpha blend).
+__global__ __launch_bounds__(256) void gather_rays_kernel(int64_t n, const int64_t* __restrict__ pix, int H, int W,
+                                                          float focal, const float* __restrict__ poses,
+                                                          int pose_stride, const uint8_t* __restrict__ images, int C,
+                                                          const float* __restrict__ lut, int white,
+                                                          float* __restrict__ ro, float* __restrict__ rd,
+                                                          float* __restrict__ target) {
+    const float hw = (float)(W * 0.5), hh = (float)(H * 0.5);
+    const int64_t hwp = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = pix[i];
+        const int64_t img = p / hwp;
+        const int64_t q = p - img * hwp;
+        const int y = (int)(q / W), x = (int)(q % W);
+        const float* c2w = poses + img * pose_stride;
+        const float dx = ((float)x - hw) / focal;
+        const float dy = ((float)y - hh) / focal;
+        const float dz = -1.0f;
+        const float wx = (dx * c2w[0] + dy * c2w[1]) + dz * c2w[2];
+        const float wy = (dx * c2w[4] + dy * c2w[5]) + dz * c2w[6];
+        const float wz = (dx * c2w[8] + dy * c2w[9]) + dz * c2w[10];
+        const float nrm = sqrtf((wx * wx + wy * wy) + wz * wz);
+        rd[3 * i + 0] = wx / nrm; rd[3 * i + 1] = wy / nrm; rd[3 * i + 2] = wz / nrm;
+        ro[3 * i + 0] = c2w[3]; ro[3 * i + 1] = c2w[7]; ro[3 * i + 2] = c2w[11];
+        if (target) {
+            const uint8_t* px = images + p * C;
+            float r = lut[px[0]], g = lut[px[1]], b = lut[px[2]];
+            if (C == 4) {
+                const float a = lut[px[3]];
+                r = r * a; g = g * a; b = b * a;                       // blender.py:103
+                if (white) { const float w1 = 1.0f - a; r = r + w1; g = g + w1; b = b + w1; }   // blender.py:100
+            }
+            target[3 * i + 0] = r; target[3 * i + 1] = g; target[3 * i + 2] = b;
         }
     }
 }
@@ -104,6 +144,23 @@ extern "C" int nerf_get_rays(int H, int W, float focal, const float* c2w, int c2
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(nerf::get_rays_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, H, W,
                        focal, c2w, c2w_ld, row0, npix, rays_o, rays_d);
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_gather_rays(int64_t n, const int64_t* pix, int n_images, int H, int W, float focal,
+                                const float* poses, int pose_stride, const uint8_t* images, int channels,
+                                const float* lut, int white_bkgd, float* rays_o, float* rays_d, float* target,
+                                void* stream) {
+    NERF_REQUIRE(pix && poses && rays_o && rays_d, NERF_E_NULL);
+    NERF_REQUIRE((target == nullptr) || (images && lut), NERF_E_NULL);
+    NERF_REQUIRE(n >= 0 && n_images >= 1 && H > 0 && W > 0 && pose_stride >= 12, NERF_E_SHAPE);
+    NERF_REQUIRE(channels == 3 || channels == 4 || target == nullptr, NERF_E_SHAPE);
+    NERF_REQUIRE(focal != 0.0f, NERF_E_SHAPE);
+    if (n == 0) return NERF_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nerf::gather_rays_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, pix, H,
+                       W, focal, poses, pose_stride, images, channels, lut, white_bkgd, rays_o, rays_d, target);
     return nerf_launch_status();
 }
 

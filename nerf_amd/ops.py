@@ -78,6 +78,38 @@ def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor, row0: int = 0,
     return ro, rd
 
 
+def gather_rays(pix: torch.Tensor, H: int, W: int, focal: float, poses: torch.Tensor,
+                images: Optional[torch.Tensor] = None, lut: Optional[torch.Tensor] = None,
+                white_bkgd: bool = False):
+    """Rays (and blended target colours when ``images`` is given) of the global pixel ids ``pix``
+    (image*H*W + y*W + x) of an image bank: (rays_o, rays_d, target or None), each [n, 3]."""
+    poses = _gpu_f32(poses, "poses")
+    if poses.dim() != 3 or poses.shape[1] not in (3, 4) or poses.shape[2] != 4:
+        raise ValueError(f"poses must be [n_images, 4, 4] or [n_images, 3, 4], got {tuple(poses.shape)}")
+    dev = poses.device
+    if pix.device != dev or pix.dtype != torch.int64 or pix.dim() != 1:
+        raise RuntimeError("pix must be a 1-D int64 tensor on the poses' device")
+    pix = pix.contiguous()
+    n, n_img = pix.numel(), poses.shape[0]
+    ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    tgt, C = None, 0
+    if images is not None:
+        if (images.device != dev or images.dtype != torch.uint8 or images.dim() != 4 or not images.is_contiguous()
+                or tuple(images.shape[:3]) != (n_img, int(H), int(W)) or images.shape[3] not in (3, 4)):
+            raise RuntimeError("images must be a contiguous uint8 [n_images, H, W, 3|4] tensor on the poses' device")
+        lut = _gpu_f32(lut, "lut")
+        if lut.numel() != 256:
+            raise ValueError("lut must hold 256 floats")
+        C = images.shape[3]
+        tgt = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nerf_gather_rays(n, _p(pix), n_img, int(H), int(W), float(focal), _p(poses),
+                                   poses.shape[1] * 4, _p(images), C, _p(lut), int(bool(white_bkgd)), _p(ro), _p(rd),
+                                   _p(tgt), _stream(dev)), "nerf_gather_rays")
+    return ro, rd, tgt
+
+
 def posenc(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
     x = _gpu_f32(x, "x")
     d = x.shape[-1]

@@ -87,13 +87,54 @@ class FlatAdam:
         for p in self.params:
             torch._C._increment_version(p)
 
+    # -- torch.optim.Adam's state_dict layout, so that checkpoints move both ways -----------------------
+    def current_step(self) -> int:
+        """Optimizer steps taken so far (from the device counter when the graph path is in use)."""
+        dev = getattr(self, "_dev_state", None)
+        return max(self.steps, int(dev[5].item())) if dev is not None else self.steps
+
     def state_dict(self):
-        return {"steps": self.steps, "lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps,
-                "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
+        """Same layout as ``torch.optim.Adam.state_dict()`` (what train_nerf.py:126 stores): per-parameter
+        ``step`` / ``exp_avg`` / ``exp_avg_sq`` under ``state`` and one entry in ``param_groups``."""
+        step = float(self.current_step())
+        state, off = {}, 0
+        if step > 0:
+            for i, (p, n) in enumerate(zip(self.params, self.sizes)):
+                state[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+                off += n
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd) -> None:
-        self.steps = int(sd["steps"])
-        self.param_groups[0]["lr"] = float(sd["lr"])
-        self.betas, self.eps = tuple(sd["betas"]), float(sd["eps"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts the dict written by ``torch.optim.Adam`` (a reference checkpoint) or by this class."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("optimizer state does not match: expected one parameter group with "
+                             f"{len(self.params)} parameters")
+        g = groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FlatAdam implements plain Adam (no weight decay, amsgrad or maximize)")
+        self.param_groups[0]["lr"] = float(g["lr"])
+        self.betas, self.eps = (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
+        steps, off = set(), 0
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for i, (p, n) in enumerate(zip(self.params, self.sizes)):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of parameter {i} has shape {tuple(st['exp_avg'].shape)}, "
+                                     f"expected {tuple(p.shape)}")
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            off += n
+        if len(steps) > 1:
+            raise ValueError(f"parameters were stepped a different number of times: {sorted(steps)}")
+        self.steps = steps.pop() if steps else 0
+        if getattr(self, "_dev_state", None) is not None:
+            b1, b2 = self.betas
+            self._dev_state[:4].copy_(torch.tensor([self.param_groups[0]["lr"], b1, b2, self.eps]))
+            self._dev_state[5] = float(self.steps)

@@ -70,6 +70,12 @@ class TrainStep:
             self._optimizer()
         # capture only records: nothing ran, so neither the weights nor the step counter moved
 
+    def prepare(self) -> None:
+        """Capture the graphs now instead of on the first call.  Capturing runs the forward and backward
+        a few times on the current buffers (consuming random numbers) but does not step the optimizer."""
+        if self.use_graph and self._g_fb is None:
+            self._capture()
+
     def __call__(self, rays_o: torch.Tensor, rays_d: torch.Tensor, target_rgb: torch.Tensor,
                  lr: Optional[float] = None) -> torch.Tensor:
         """One optimisation step on this rank's rays; returns the (device) total loss of this rank."""

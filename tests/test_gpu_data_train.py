@@ -1,0 +1,160 @@
+"""GPU tests of the rows either side of the hot path: the Blender loader with its GPU ray sampler
+(datasets/blender.py:34-164), optimizer-state interchange with torch.optim.Adam, and the training loop
+with checkpoint / resume (scripts/train_nerf.py:109-137, :219-260, :272-383).
+
+Loader parity is against the oracle restatement only (the reference's loader needs imageio, which is
+not installed, and the reference ships no data): bit-exact for colours and ray origins, 2e-7 abs for
+the unit ray directions (fp32 division and sqrt differ from the CPU's by <= 1 ulp); the batched sampler is
+bit-identical to the per-image kernel."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from util import O, make_blender_scene
+from oracle import blender_oracle as BO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _same(k, got, want):
+    if k == "rays_d":
+        return got.shape == want.shape and (got.cpu() - want).abs().max().item() < 2e-7
+    return got.shape == want.shape and torch.equal(got.cpu(), want)
+
+
+def _read(path):
+    from nerf_amd.utils.png import read_png
+    return read_png(path)
+
+
+@pytest.mark.parametrize("channels,white", [(4, False), (4, True), (3, True)])
+def test_blender_dataset_matches_oracle(tmp_path, channels, white):
+    from nerf_amd.datasets import BlenderDataset
+    root = str(tmp_path)
+    make_blender_scene(root, n_images=5, H=10, W=12, channels=channels, missing=(3,))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ds = BlenderDataset(root, "train", data_white_bkgd=white)
+    assert any("skipping frame 3" in str(x.message) for x in w)           # blender.py:79-86
+    ref = BO.load_blender(root, "train", white, _read)
+    assert len(ds) == 4 and ds.image_paths == ref["image_paths"]
+    assert (ds.height, ds.width) == (10, 12) and ds.focal == float(ref["focal"])
+    assert torch.equal(ds.poses.cpu(), ref["poses"])
+    assert torch.equal(ds.all_rgbs.cpu(), ref["all_rgbs"])                # bit-exact colours
+    for idx in (0, 3, -1):
+        got, want = ds[idx], BO.item(ref, idx, "train")
+        assert set(got) == {"rays_o", "rays_d", "target_rgb"}
+        for k in got:
+            assert _same(k, got[k], want[k]), k
+    val = BlenderDataset(root, "val", data_white_bkgd=white)
+    refv = BO.load_blender(root, "val", white, _read)
+    got, want = val[1], BO.item(refv, 1, "val")
+    assert set(got) == {"rays_o", "rays_d", "target_rgb", "pose"} and got["rays_o"].shape == (10, 12, 3)
+    for k in got:
+        assert _same(k, got[k], want[k]), k
+    # ray batches drawn across images are the same rays the per-image path produces
+    g = torch.Generator(device=DEV).manual_seed(1)
+    pix = torch.randint(0, ds.num_rays, (333,), device=DEV, generator=g)
+    ro, rd, tg = ds.gather(pix)
+    img, q = (pix // 120).cpu(), (pix % 120).cpu()
+    per_image = [ds[i] for i in range(len(ds))]
+    for k, t in (("rays_o", ro), ("rays_d", rd), ("target_rgb", tg)):
+        want = torch.stack([per_image[int(i)][k][int(j)] for i, j in zip(img, q)])
+        assert torch.equal(t, want), k
+    # two ranks with the same generator state split one batch
+    g0, g1 = torch.Generator(device=DEV).manual_seed(5), torch.Generator(device=DEV).manual_seed(5)
+    a, b = ds.sample_rays(64, g0, 0, 2), ds.sample_rays(64, g1, 1, 2)
+    whole = ds.sample_rays(128, torch.Generator(device=DEV).manual_seed(5))
+    assert torch.equal(torch.cat([a[2], b[2]]), whole[2]) and torch.equal(torch.cat([a[1], b[1]]), whole[1])
+    with pytest.raises(IndexError):
+        ds.gather(torch.tensor([ds.num_rays], device=DEV))
+    with pytest.raises(FileNotFoundError):
+        BlenderDataset(root, "test")
+
+
+def test_flat_adam_state_interchange():
+    """FlatAdam <-> torch.optim.Adam through state_dict (the 'optimizer_state_dict' of a checkpoint)."""
+    from nerf_amd.optim import FlatAdam
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(7, 5), (5,), (3, 7), (3,)]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+    grads = [[torch.randn(s, generator=gen) * 0.1 for s in shapes] for _ in range(6)]
+    ref_p = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = torch.optim.Adam(ref_p, lr=1e-2)
+    mine_p = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    mine = FlatAdam(mine_p, lr=1e-2)
+
+    def run(opt, ps, gs):
+        for p, g in zip(ps, gs):
+            p.grad = g.clone().to(DEV)
+        opt.step()
+
+    for s in range(3):
+        run(ref, ref_p, grads[s])
+    mine.load_state_dict(ref.state_dict())            # continue torch's run with the flat optimizer
+    with torch.no_grad():
+        for p, q in zip(mine_p, ref_p):
+            p.copy_(q)
+    assert mine.current_step() == 3
+    for s in range(3, 6):
+        run(ref, ref_p, grads[s]); run(mine, mine_p, grads[s])
+    for p, q in zip(mine_p, ref_p):
+        assert torch.allclose(p, q, rtol=0, atol=2e-6)
+    sd = mine.state_dict()                            # and back: torch loads what the flat optimizer wrote
+    back_p = [torch.nn.Parameter(p.detach().clone()) for p in mine_p]
+    back = torch.optim.Adam(back_p, lr=1.0)
+    back.load_state_dict(sd)
+    assert back.param_groups[0]["lr"] == 1e-2
+    for i, q in enumerate(ref_p):
+        assert float(back.state[back_p[i]]["step"]) == 6.0
+        assert torch.allclose(back.state[back_p[i]]["exp_avg"], ref.state[q]["exp_avg"], rtol=1e-4, atol=1e-8)
+        assert torch.allclose(back.state[back_p[i]]["exp_avg_sq"], ref.state[q]["exp_avg_sq"], rtol=1e-4, atol=1e-10)
+    with pytest.raises(ValueError):
+        FlatAdam([torch.nn.Parameter(torch.zeros(3, device=DEV))]).load_state_dict(sd)
+
+
+def test_trainer_checkpoint_resume(tmp_path):
+    """30 steps on a tiny scene: the loss goes down, a checkpoint in the reference's format is written,
+    and a new trainer resumed from it takes bit-identical further steps; the checkpoint renders."""
+    from nerf_amd import checkpoint as C
+    from nerf_amd.datasets import BlenderDataset
+    from nerf_amd.render import render_image
+    from nerf_amd.trainer import TrainConfig, Trainer
+    root = str(tmp_path / "scene")
+    make_blender_scene(root, n_images=4, H=16, W=16, channels=4, splits=("train",))
+    ds = BlenderDataset(root, "train", data_white_bkgd=True)
+    cfg = TrainConfig(expname="t", basedir=str(tmp_path / "logs"), batch_size=256, log_freq=5, save_freq=1,
+                      white_bkgd=True, precision="fp16", lr=1e-3)
+    logs = []
+    tr = Trainer(ds, cfg, log=logs.append)
+    assert tr.steps_per_epoch == 4                                   # 4 images * 256 px / 256 rays
+    tr.fit(num_epochs=5)                                             # 20 steps, 5 + 1 checkpoints
+    first, last = tr.history[0]["loss"], tr.history[-1]["loss"]
+    assert np.isfinite(last) and last < first
+    assert any(m.startswith("GS: 5 LR: 0.0010000 Loss_T: ") for m in logs)
+    files = sorted(os.listdir(tr.checkpoint_dir()))
+    assert "latest.pth" in files and "checkpoint_final_epoch_0004_step_0000020.pth" in files
+    assert "checkpoint_epoch_0002_step_0000012.pth" in files
+    ck = C.load_checkpoint(os.path.join(tr.checkpoint_dir(), "latest.pth"))
+    assert ck["global_step"] == 20 and ck["epoch"] == 4 and ck["H"] == 16 and abs(ck["focal"] - ds.focal) < 1e-9
+    assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 20.0
+
+    tr2 = Trainer(ds, cfg, log=None)
+    tr2.resume("latest.pth")
+    assert (tr2.epoch, tr2.global_step, tr2.optimizer.current_step()) == (5, 20, 20)
+    # same sampler position as the first trainer after 20 steps
+    tr2.sampler.set_state(tr.sampler.get_state())
+    tr2.step_fn.prepare()            # graph capture draws random numbers: do it before seeding
+    torch.manual_seed(123); la = [float(tr.train_step()) for _ in range(3)]
+    torch.manual_seed(123); lb = [float(tr2.train_step()) for _ in range(3)]
+    assert la == lb
+    assert torch.equal(tr.optimizer.flat, tr2.optimizer.flat)
+
+    mc, mf, pe, pv, rcfg = C.build_models(ck, precision="fp16")
+    frame = render_image(mc, mf, pe, pv, ck["H"], ck["W"], ck["focal"], ds.poses[0], near=2.0, far=6.0,
+                         white_bkgd=True)
+    assert frame.shape == (16, 16, 3) and torch.isfinite(frame).all()

@@ -26,3 +26,29 @@ def amd_model(params, precision="bf16", device="cuda", **kw):
 
 def maxabs(a, b):
     return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
+
+
+def make_blender_scene(root, n_images=5, H=10, W=12, channels=4, seed=0, splits=("train", "val"), missing=()):
+    """A tiny scene in the layout of the Blender NeRF data (transforms_<split>.json + PNG files), written
+    with the product's PNG writer; poses from the oracle's pose_spherical.  Returns the decoded images."""
+    from nerf_amd.utils.png import write_png
+    import json
+    rng = np.random.default_rng(seed)
+    images = {}
+    for split in splits:
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        frames = []
+        for i in range(n_images):
+            img = rng.integers(0, 256, size=(H, W, channels), dtype=np.uint8)
+            if channels == 4:
+                img[: H // 3, :, 3] = 0          # fully transparent band
+                img[H // 3: 2 * H // 3, :, 3] = 255
+            rel = f"./{split}/r_{i}" if i % 2 == 0 else f"{split}/r_{i}"
+            if i not in missing:
+                write_png(os.path.join(root, split, f"r_{i}.png"), img)
+                images[(split, i)] = img
+            pose = O.pose_spherical(37.0 * i + 5.0, -30.0 + 3.0 * i, 4.0)
+            frames.append({"file_path": rel, "rotation": 0.0123, "transform_matrix": pose.double().tolist()})
+        with open(os.path.join(root, f"transforms_{split}.json"), "w") as f:
+            json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, f)
+    return images
