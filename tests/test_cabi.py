@@ -55,7 +55,7 @@ def test_argument_errors_without_gpu():
     assert lib.nerf_mlp_packed_bytes() == (1184 + 1120) * 1024 + 11 * 288 * 4
     lib.nerf_mlp_saved_bytes.restype = ctypes.c_int64
     lib.nerf_mlp_saved_bytes.argtypes = [ctypes.c_int64]
-    assert lib.nerf_mlp_saved_bytes(1) == 8 * 158 * 1024 and lib.nerf_mlp_saved_bytes(257) == 16 * 158 * 1024
+    assert lib.nerf_mlp_saved_bytes(1) == 8 * (158 + 9) * 1024 and lib.nerf_mlp_saved_bytes(257) == 16 * (158 + 9) * 1024
 
 
 def test_cpu_tensors_are_rejected():
