@@ -135,6 +135,15 @@ int nerf_sort_rows(int64_t n_rows, int n_a, const float *a, int n_b, const float
                    void *stream);
 
 /* ------------------------------------------------------------------------
+ * training loss -- scripts/train_nerf.py:299, :330-331.
+ * a, b, target: n_elements floats each ([n_rays, 3] maps; b may be NULL for a coarse-only run).
+ * losses[0..2] = { mean((a-t)^2) + mean((b-t)^2), mean((a-t)^2), mean((b-t)^2) }.
+ * d_a, d_b (nullable): gradients of the two means, 2 (x - t) / n_elements.
+ */
+int nerf_mse_pair(int64_t n_elements, const float *a, const float *b, const float *target, float *losses,
+                  float *d_a, float *d_b, void *stream);
+
+/* ------------------------------------------------------------------------
  * Fused positional encoding + MLP -- models/nerf.py:68-76 (PositionalEncoder,
  * L=10 for points, L=4 for view directions, frequencies 2^l, no pi) and
  * models/nerf.py:173-209 (NeRF.forward, D=8, W=256, skips=[4], use_viewdirs).

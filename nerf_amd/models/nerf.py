@@ -50,6 +50,19 @@ class PositionalEncoder(nn.Module):
         return ops.posenc(x, self.freq_bands)
 
 
+def _consecutive_view(ps) -> Optional[torch.Tensor]:
+    """The parameters as one flat tensor without copying, when they already lie back to back in one
+    storage (as they do once ``FlatAdam`` has moved them into its bucket); else None."""
+    store = ps[0].untyped_storage().data_ptr()
+    ptr, total = ps[0].data_ptr(), 0
+    for p in ps:
+        if (not p.is_contiguous() or p.dtype != torch.float32 or p.untyped_storage().data_ptr() != store
+                or p.data_ptr() != ptr + 4 * total):
+            return None
+        total += p.numel()
+    return ps[0].detach().as_strided((total,), (1,), ps[0].storage_offset())
+
+
 class NeRF(nn.Module):
     """The NeRF MLP with the reference's parameters (nerf.py:126-153) and forward (nerf.py:173-209).
 
@@ -119,7 +132,9 @@ class NeRF(nn.Module):
         key = None if training else (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)
         if training or key != self._pack_key:
             with torch.no_grad():
-                flat = torch.cat([p.detach().reshape(-1) for p in ps])
+                flat = _consecutive_view(ps)
+                if flat is None:
+                    flat = torch.cat([p.detach().reshape(-1) for p in ps])
                 self._packed = ops.mlp_pack(flat, self.precision)
             self._pack_key = key
         return self._packed

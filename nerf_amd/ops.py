@@ -187,6 +187,7 @@ class _Composite(torch.autograd.Function):
                   "nerf_composite_fwd")
         ctx.save_for_backward(raw, z)
         ctx.white = bool(white_bkgd)
+        ctx.set_materialize_grads(False)      # unused outputs arrive as None, not as tensors of zeros
         return rgb, depth, disp, acc, weights, alpha
 
     @staticmethod
@@ -205,6 +206,41 @@ class _Composite(torch.autograd.Function):
                                          _p(g_acc), _p(g_w), _p(g_alpha), _p(d_raw), _stream(dev)),
                   "nerf_composite_bwd")
         return d_raw, None, None
+
+
+class _MsePair(torch.autograd.Function):
+    """(total, loss_a, loss_b) of train_nerf.py:299, :330-331; only ``total`` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, a, b, target, out):
+        a, b, target = _gpu_f32(a, "rgb_coarse"), _gpu_f32(b, "rgb_fine"), _gpu_f32(target, "target_rgb")
+        if a.shape != target.shape or b.shape != target.shape:
+            raise ValueError(f"rgb maps and target must agree in shape: {tuple(a.shape)}, {tuple(b.shape)}, "
+                             f"{tuple(target.shape)}")
+        dev = a.device
+        losses = out if out is not None else torch.empty((3,), dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        da = torch.empty_like(a) if need else None
+        db = torch.empty_like(b) if need else None
+        with torch.cuda.device(dev):
+            check(lib.nerf_mse_pair(a.numel(), _p(a), _p(b), _p(target), _p(losses), _p(da), _p(db), _stream(dev)),
+                  "nerf_mse_pair")
+        ctx.save_for_backward(da, db)
+        total, la, lb = losses[0], losses[1], losses[2]
+        ctx.mark_non_differentiable(la, lb)
+        return total, la, lb
+
+    @staticmethod
+    def backward(ctx, g_total, _ga, _gb):
+        da, db = ctx.saved_tensors
+        return g_total * da, g_total * db, None, None
+
+
+def mse_pair(rgb_coarse: torch.Tensor, rgb_fine: torch.Tensor, target: torch.Tensor,
+             out: Optional[torch.Tensor] = None):
+    """Both photometric losses and their sum in one launch: (total, loss_coarse, loss_fine), scalars
+    that are views of one 3-float tensor (``out`` if given).  Gradients flow through ``total``."""
+    return _MsePair.apply(rgb_coarse, rgb_fine, target, out)
 
 
 def composite(raw: torch.Tensor, z_vals: torch.Tensor, white_bkgd: bool = False):

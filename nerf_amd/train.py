@@ -13,6 +13,7 @@ from typing import Optional
 
 import torch
 
+from . import ops
 from .models.nerf import render_hierarchical
 from .optim import FlatAdam
 from .parallel import allreduce_gradients_
@@ -31,25 +32,26 @@ class TrainStep:
         self.rays_o = torch.zeros((n_rays, 3), device=dev)
         self.rays_d = torch.zeros((n_rays, 3), device=dev)
         self.target = torch.zeros((n_rays, 3), device=dev)
-        self.loss = torch.zeros((), device=dev)
-        self.loss_coarse = torch.zeros((), device=dev)
-        self.loss_fine = torch.zeros((), device=dev)
+        self.losses = torch.zeros((3,), device=dev)           # total, coarse, fine: written by the loss kernel
+        self.loss, self.loss_coarse, self.loss_fine = self.losses[0], self.losses[1], self.losses[2]
         self._g_fb: Optional[torch.cuda.CUDAGraph] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
         self.opt.device_state()[4] = 1.0 / world_size        # gradients are summed over ranks, then averaged
 
     # the step body: losses of train_nerf.py:299, :330-331; gradients into the optimizer's flat bucket
     def _forward_backward(self):
+        # the three uniform draws of a step (train_nerf.py:296, :317, :327) come from one generator call
+        n, nc, nf = self.rays_o.shape[0], self.nc, self.nf
+        r = torch.rand((n * (2 * nc + 2 * nf),), dtype=torch.float32, device=self.rays_o.device)
+        t_c, u_f, t_f = (r[:n * nc].view(n, nc), r[n * nc:n * (nc + nf)].view(n, nf),
+                         r[n * (nc + nf):].view(n, nc + nf))
         coarse, fine = render_hierarchical(self.mc, self.mf, self.pe, self.pv, self.rays_o, self.rays_d, self.near,
                                            self.far, self.nc, self.nf, rand=True, det=False, lindisp=self.lindisp,
-                                           white_bkgd=self.white)
-        lc = torch.mean((coarse["rgb_map"] - self.target) ** 2)
-        lf = torch.mean((fine["rgb_map"] - self.target) ** 2)
-        total = lc + lf
+                                           white_bkgd=self.white, t_rand_coarse=t_c, u_fine=u_f, t_rand_fine=t_f)
+        total, _, _ = ops.mse_pair(coarse["rgb_map"], fine["rgb_map"], self.target, out=self.losses)
         self.opt.zero_grad(set_to_none=True)
         total.backward()
         self.opt.gather_grads()
-        self.loss_coarse.copy_(lc.detach()); self.loss_fine.copy_(lf.detach()); self.loss.copy_(total.detach())
 
     def _optimizer(self):
         self.opt.step_dev(grads_gathered=True)

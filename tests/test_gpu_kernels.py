@@ -364,3 +364,28 @@ def test_render_e2e_golden(amd, golden, precision):
                 raw_tol = {"bf16": 1e-3, "fp16": 1.5e-4}[precision]
                 assert maxabs(f2["raw_sigma"], T(g["f_raw_sigma_l0w0"])) < raw_tol
                 assert maxabs(c["raw_sigma"], T(g["c_raw_sigma_l0w0"])) < raw_tol
+
+
+def test_mse_pair_matches_torch(amd):
+    """loss of train_nerf.py:299, :330-331 and its gradients against the ATen spelling"""
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    for n in (1, 257, 1024, 5000):
+        a0, b0, t = (torch.rand(n, 3, generator=gen).to(DEV) for _ in range(3))
+        a1, b1 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        want = torch.mean((a1 - t) ** 2) + torch.mean((b1 - t) ** 2)
+        (want * 3.0).backward()
+        a2, b2 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = torch.zeros(3, device=DEV)
+        total, la, lb = ops.mse_pair(a2, b2, t, out=out)
+        (total * 3.0).backward()
+        assert abs(total.item() - want.item()) < 1e-6 * want.item()
+        assert abs(la.item() - torch.mean((a0 - t) ** 2).item()) < 1e-6 and abs(out[2].item() - lb.item()) == 0.0
+        assert not la.requires_grad and total.requires_grad
+        assert torch.allclose(a2.grad, a1.grad, rtol=1e-6, atol=1e-12)
+        assert torch.allclose(b2.grad, b1.grad, rtol=1e-6, atol=1e-12)
+    with torch.no_grad():
+        total, _, _ = ops.mse_pair(a0, b0, t)
+        assert not total.requires_grad
+    with pytest.raises(ValueError):
+        ops.mse_pair(a0, b0[:-1], t)
