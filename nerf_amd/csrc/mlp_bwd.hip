@@ -98,7 +98,7 @@ __device__ __forceinline__ typename Prec<PREC>::frag load_unit_frag(const char* 
 template <int PREC>
 __device__ __forceinline__ void store_unit_frag(char* base, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
                                                 int lane_off, const typename Prec<PREC>::frag& f) {
-    *reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
+    __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
 }
 
 // accumulator tile (gradient w.r.t. a post-ReLU activation) -> 16-bit fragments, zeroed where the
@@ -135,7 +135,7 @@ __device__ __forceinline__ void mask_issue(const char* masks, int64_t wt, int te
                                            int lane) {
     gbl_char* g = (gbl_char*)(masks + ((size_t)wt * MASK_TENSORS + tensor) * 1024) + lane * 16;
     lds_char* l = (lds_char*)(lds + MASK_LDS_OFF + buf * MASK_BUF_BYTES + wave * 1024);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 2);      // read once: non-temporal
 }
 __device__ __forceinline__ void mask_landed() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
@@ -167,7 +167,10 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
         mask_issue(masks, wt, 7, lds, MB_A, wave, lane);
 
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid && h == 0) dr = reinterpret_cast<const float4*>(a.d_raw)[m];
+        if (valid && h == 0) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.d_raw) + m);
+            dr = make_float4(v[0], v[1], v[2], v[3]);
+        }
         dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale;
 
         frag da[H_KS + 1], db[H_KS];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
 constexpr int WG_STAGES = 4;                  // one being read, up to three in flight
 constexpr int WG_STAGE_BYTES = 32 * 1024;     // up to 16 A units + 16 B units
 #ifndef NERF_WG_DMA_AUX
-#define NERF_WG_DMA_AUX 0
+#define NERF_WG_DMA_AUX 2
 #endif
 constexpr int WG_DMA_AUX = NERF_WG_DMA_AUX;    // cache policy bits of the streaming copies (2 = nt)
 constexpr int WG_LDS_BYTES = WG_STAGES * WG_STAGE_BYTES;

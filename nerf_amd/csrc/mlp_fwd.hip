@@ -86,7 +86,7 @@ __device__ __forceinline__ void gather_encoded(const float* __restrict__ x, int6
 template <int PREC>
 __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
                                           int lane_off, const typename Prec<PREC>::frag& f) {
-    *reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
+    __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
 }
 
 // signs of one finished output tile (already ReLU'd and rounded: 16-bit values with a clear top bit),
