@@ -36,6 +36,23 @@ MLP_WGRAD_FLOP = 2 * 593408
 MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 peak, MI355X
 HBM_PEAK_GBS = 8000.0
 WGRAD_BYTES_PER_SAMPLE = 312 * 1024 // 32   # saved activations (158 KiB) + dZ (154 KiB) per 32 samples
+# HBM bytes per launch measured with rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as
+# gfx950 requires for wide streams, plus WRITE_SIZE), written by scratch/summarize_prof.py
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def measured_traffic(kernel, rays_per_gpu, precision):
+    """HBM bytes per launch of `kernel` from the committed PMC summary, or None when the summary was
+    taken for another workload."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get("rays_per_gpu") != rays_per_gpu or t.get("precision") != precision:
+        return None
+    e = t.get("kernels", {}).get(kernel)
+    return None if e is None else e.get("hbm_bytes_per_launch")
 
 
 def parse():
@@ -46,9 +63,11 @@ def parse():
     ap.add_argument("--rays-per-gpu", type=int, default=1024)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-render", action="store_true", help="skip the 800x800 frame render measurement")
-    ap.add_argument("--render-chunk", type=int, default=65536)
+    ap.add_argument("--render-chunk", type=int, nargs="+", default=[65536, 4096],
+                    help="rays per launch group of the frame render; the first value is the headline one, "
+                         "4096 is the reference's eval_batch_size (render_nerf.py:55)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying HIP graphs")
     ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
     return ap.parse_args()
@@ -68,43 +87,49 @@ def build(device, precision):
 def render_section(mc, mf, pe, pv, device, args):
     """BASELINE.json configs[2]: one 800x800 frame (640 000 rays, 64 + 128 samples, deterministic, no_grad),
     rays generated on the GPU, rendered in chunks.  Reports rays/s and the achieved rates of the MLP
-    forward (MFMA) and of the compositing / ray-generation kernels (HBM)."""
+    forward (MFMA) and of the compositing / sampling / ray-generation kernels (HBM, algorithmic bytes)."""
     from nerf_amd import ops
     from nerf_amd.render import render_image
     from nerf_amd.utils.synthetic import focal_from_fov, pose_spherical
     H = W = 800
     c2w = pose_spherical(0.0, -30.0, 4.0).to(device)
     focal = focal_from_fov(W)
-    render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=args.render_chunk)          # warm-up
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    frames = 2
-    for _ in range(frames):
-        render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=args.render_chunk)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / frames
-    ops.KERNEL_TIMES = {}
-    render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=args.render_chunk)
-    torch.cuda.synchronize()
-    times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
-    sec = {"workload": "800x800 frame, 640000 rays, 64+128 samples, chunk %d, no_grad, deterministic" % args.render_chunk,
-           "s_per_frame": round(dt, 4), "rays_per_s": round(H * W / dt, 1), "kernels": {}}
-    for name, evs in sorted(times.items()):
-        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-        units = sum(u for _, _, u in evs)
-        e = {"total_ms": round(tot_ms, 3), "launches": len(evs)}
-        if name == "mlp_fwd":
-            e["TFLOP/s"] = round(units * MLP_FWD_FLOP / (tot_ms * 1e-3) / 1e12, 1)
-            e["frac_of_mfma_peak"] = round(e["TFLOP/s"] / MFMA_PEAK_TFLOPS, 4)
-        elif name.startswith("composite_fwd"):
-            S = int(name.rsplit("S", 1)[1])
-            e["GB/s"] = round(units * (28 * S + 24) / (tot_ms * 1e-3) / 1e9, 1)     # alpha is written too: +4S
-            e["frac_of_hbm_peak"] = round(e["GB/s"] / HBM_PEAK_GBS, 4)
-        elif name == "get_rays":
-            e["GB/s"] = round(units * 24 / (tot_ms * 1e-3) / 1e9, 1)
-            e["frac_of_hbm_peak"] = round(e["GB/s"] / HBM_PEAK_GBS, 4)
-        sec["kernels"][name] = e
-    return sec
+    out = []
+    for chunk in args.render_chunk:
+        render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=chunk)          # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames = 2
+        for _ in range(frames):
+            render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=chunk)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames
+        ops.KERNEL_TIMES = {}
+        render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=chunk)
+        torch.cuda.synchronize()
+        times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+        sec = {"workload": "800x800 frame, 640000 rays, 64+128 samples, chunk %d, no_grad, deterministic" % chunk,
+               "s_per_frame": round(dt, 4), "rays_per_s": round(H * W / dt, 1), "kernels": {}}
+        for name, evs in sorted(times.items()):
+            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+            units = sum(u for _, _, u in evs)
+            e = {"total_ms": round(tot_ms, 3), "launches": len(evs)}
+            per_unit = None
+            if name == "mlp_fwd":
+                e["TFLOP/s"] = round(units * MLP_FWD_FLOP / (tot_ms * 1e-3) / 1e12, 1)
+                e["frac_of_mfma_peak"] = round(e["TFLOP/s"] / MFMA_PEAK_TFLOPS, 4)
+            elif name.startswith("composite_fwd"):
+                per_unit = 28 * int(name.rsplit("S", 1)[1]) + 24       # raw 16S + z 4S in; weights, alpha 8S + maps out
+            elif name == "get_rays":
+                per_unit = 24
+            elif name == "sample_merge_det":
+                per_unit = 64 * 4 * 2 + 192 * 4                         # z, weights [64] in; sorted z [192] out
+            if per_unit is not None:
+                e["GB/s"] = round(units * per_unit / (tot_ms * 1e-3) / 1e9, 1)
+                e["frac_of_hbm_peak"] = round(e["GB/s"] / HBM_PEAK_GBS, 4)
+            sec["kernels"][name] = e
+        out.append(sec)
+    return out
 
 
 def cpu_baseline(n_rays, steps):
@@ -213,7 +238,11 @@ def main():
             achieved = units * flop[dom] / (avg_ms * 1e-3) / 1e12
             rl = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flop[dom]}
-        roofline = {"kernel": dom, **rl, "traffic": None,
+        traffic = measured_traffic(dom, n, args.precision)
+        roofline = {"kernel": dom, **rl, "traffic": traffic,
+                    "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 PMC passes of this "
+                                    "command, profiles/traffic.json" if traffic is not None else "not collected",
+                    "algorithmic_bytes_per_launch": round(units * WGRAD_BYTES_PER_SAMPLE) if rl["bound"] == "hbm" else None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
                     "samples_per_launch": units,
                     "timing": "HIP events on the launch stream around each launch, %d eager steps of the same "
@@ -228,9 +257,12 @@ def main():
                 if k == "mlp_bwd_weights":
                     entry["GB/s"] = round(u * WGRAD_BYTES_PER_SAMPLE / (a_ms * 1e-3) / 1e9, 1)
                     entry["frac_of_hbm_peak"] = round(entry["GB/s"] / HBM_PEAK_GBS, 4)
-            elif k.startswith("composite"):
-                S = int(k.rsplit("S", 1)[1])
-                per_ray = (24 * S + 24) if "fwd" in k else (36 * S + 24)
+            elif k.startswith("composite") or k.startswith("sample_merge"):
+                if k.startswith("composite"):
+                    S = int(k.rsplit("S", 1)[1])
+                    per_ray = (28 * S + 24) if "fwd" in k else (36 * S + 24)    # fwd also writes alpha [S]
+                else:
+                    per_ray = 64 * 4 * 2 + (128 * 4 if k.endswith("_u") else 0) + 192 * 4
                 entry["GB/s"] = round(u * per_ray / (a_ms * 1e-3) / 1e9, 1)
                 entry["frac_of_hbm_peak"] = round(entry["GB/s"] / HBM_PEAK_GBS, 4)
             kernels[k] = entry

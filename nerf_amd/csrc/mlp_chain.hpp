@@ -70,7 +70,9 @@ template <int YOUNGER = 0>
 __device__ __forceinline__ void ring_enter(Ring& r, char* lds) {
     static_assert(DMA_PER_CHUNK + YOUNGER <= 63, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK + YOUNGER) : "memory");
+#ifndef NERF_ABL_NO_BARRIER          // timing experiment only: results are wrong without the barrier
     __builtin_amdgcn_s_barrier();
+#endif
     r.slot = r.slot == RING_SLOTS - 1 ? 0 : r.slot + 1;
     int refill = r.slot + 2;
     if (refill >= RING_SLOTS) refill -= RING_SLOTS;
@@ -99,7 +101,10 @@ __device__ __forceinline__ f32x16 bias_tile(const float* bias_lds, int layer, in
 // layer's first block in the stream; init(m) gives the starting accumulator of tile m and
 // epi(m, acc) consumes the finished tile.  A fragments are read PF blocks ahead of their MFMA,
 // never across a chunk entry (the data is only known to have landed after its barrier).
-constexpr int PF = 3;
+#ifndef NERF_PF
+#define NERF_PF 3
+#endif
+constexpr int PF = NERF_PF;
 // last block (layer-relative) that may have been requested once step i runs: i+PF, clipped to the
 // layer and to the chunk that block i lives in
 constexpr int pf_hi(int B0, int NB, int i) {

@@ -319,7 +319,7 @@ def sample_merge(z_coarse: torch.Tensor, weights_coarse: torch.Tensor, N_fine: i
             raise ValueError(f"u must be [{N}, {N_fine}], got {tuple(u.shape)}")
     out = torch.empty((N, Sc + N_fine), dtype=torch.float32, device=dev)
     zf = torch.empty((N, N_fine), dtype=torch.float32, device=dev) if return_fine else None
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("sample_merge_det" if u is None else "sample_merge_u", dev, N):
         check(lib.nerf_sample_merge(N, Sc, _p(zc), _p(wc), int(N_fine), _p(u), _p(out), _p(zf), _stream(dev)),
               "nerf_sample_merge")
     return (out, zf) if return_fine else out

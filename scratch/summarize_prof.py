@@ -1,36 +1,97 @@
-"""Summarise rocprofv3 CSVs under gpurun_out/prof_r1 into small text files for profiles/."""
-import csv, sys, collections, os, re
-src = sys.argv[1]; dst = sys.argv[2]
+"""Summarise the rocprofv3 CSVs of scratch/prof.sh into small text files for profiles/<tag>/ and the
+per-launch HBM traffic table profiles/traffic.json that bench.py reports as roofline.traffic.
+
+    python scratch/summarize_prof.py gpurun_out/prof_<tag> profiles/<tag>
+"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
+cmd = open(os.path.join(src, "command.txt")).read().strip()
+
+# bench.py's kernel names -> device kernel names
+BENCH_NAMES = {"mlp_bwd_weights": "mlp_wgrad_kernel", "mlp_bwd_data": "mlp_dgrad_kernel",
+               "mlp_fwd_train": "mlp_fwd_kernel<0, true, false>", "mlp_fwd": "mlp_fwd_kernel<0, false, false>"}
+
+
 def short(n):
     n = re.sub(r"\(.*", "", n)
-    n = n.replace("void ", "")
-    return n[:90]
+    return n.replace("void ", "")[:90]
+
+
 def find(sub, name):
     for root, _, files in os.walk(os.path.join(src, sub)):
         for f in files:
-            if f.endswith(name): return os.path.join(root, f)
-# kernel stats
-p = find("trace", "kernel_stats.csv")
-rows = list(csv.DictReader(open(p)))
+            if f.endswith(name):
+                return os.path.join(root, f)
+    raise FileNotFoundError(f"{sub}/**/{name}")
+
+
+rows = list(csv.DictReader(open(find("trace", "kernel_stats.csv"))))
 with open(os.path.join(dst, "kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --kernel-steps 2\n")
-    f.write("# (10 timed graph-replayed steps + 3 warm-up + 5 eager steps + render section: 4 frames of 800x800)\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}\n")
+    f.write("# (3 warm-up + 10 timed graph-replayed training steps, 3 eager steps, then the frame renders)\n")
     f.write(f"{'kernel':92s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}\n")
-    for r in rows[:28]:
-        f.write(f"{short(r['Name']):92s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.1f} {float(r['MinNs'])/1e3:10.1f} {float(r['MaxNs'])/1e3:10.1f} {float(r['Percentage']):7.2f}\n")
-# pmc
-def pmc(sub, out, note):
-    p = find(sub, "counter_collection.csv")
+    for r in rows[:30]:
+        f.write(f"{short(r['Name']):92s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.1f} "
+                f"{float(r['MinNs'])/1e3:10.1f} {float(r['MaxNs'])/1e3:10.1f} {float(r['Percentage']):7.2f}\n")
+
+
+def pmc(sub):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(p)):
+    for r in csv.DictReader(open(find(sub, "counter_collection.csv"))):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def write(agg, out, note):
     with open(os.path.join(dst, out), "w") as f:
         f.write(note + "\n")
         for k, cs in sorted(agg.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
-            if not any(t in k for t in ("nerf::",)): continue
-            line = f"{k:80s} n={len(next(iter(cs.values()))):4d} " + " ".join(f"{c}: mean {sum(v)/len(v):.4g} max {max(v):.4g}" for c, v in sorted(cs.items()))
-            f.write(line + "\n")
-pmc("pmc_mfma", "pmc_mfma.txt", "# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE (per dispatch; mean and max over dispatches)")
-pmc("pmc_fetch", "pmc_fetch.txt", "# rocprofv3 --pmc FETCH_SIZE (KB per dispatch as reported; on gfx950 a wide coalesced stream is under-reported 2x)")
-pmc("pmc_write", "pmc_write.txt", "# rocprofv3 --pmc WRITE_SIZE (KB per dispatch)")
+            if "nerf::" not in k:
+                continue
+            f.write(f"{k:80s} n={len(next(iter(cs.values()))):4d} " + " ".join(
+                f"{c}: mean {sum(v)/len(v):.4g} max {max(v):.4g}" for c, v in sorted(cs.items())) + "\n")
+
+
+mf, fe, wr = pmc("pmc_mfma"), pmc("pmc_fetch"), pmc("pmc_write")
+write(mf, "pmc_mfma.txt", f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -- {cmd}\n"
+      "# per dispatch; MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)")
+write(fe, "pmc_fetch.txt", f"# rocprofv3 --pmc FETCH_SIZE -- {cmd}\n# KiB per dispatch as reported; gfx950 tallies a wide "
+      "coalesced stream at half its bytes")
+write(wr, "pmc_write.txt", f"# rocprofv3 --pmc WRITE_SIZE -- {cmd}\n# KiB per dispatch")
+
+with open(os.path.join(dst, "mfma_util.txt"), "w") as f:
+    f.write("# MFMA pipe busy fraction and effective clock per kernel (means over dispatches)\n")
+    stats = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+    for k, cs in mf.items():
+        if "mlp_" not in k or "SQ_VALU_MFMA_BUSY_CYCLES" not in cs:
+            continue
+        busy = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(cs["SQ_VALU_MFMA_BUSY_CYCLES"])
+        gui = sum(cs["GRBM_GUI_ACTIVE"]) / len(cs["GRBM_GUI_ACTIVE"])
+        line = f"{k:70s} mfma_busy {busy / (gui / 8 * 1024):.3f}"
+        if k in stats:
+            line += f"  clock_GHz {gui / 8 / stats[k]:.2f}"
+        f.write(line + "\n")
+
+bench = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
+traffic = {"command": cmd, "rays_per_gpu": bench["config"]["rays_per_gpu"], "precision": bench["dtype"],
+           "note": "means over the dispatches of one run; hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes)",
+           "kernels": {}}
+for bname, kname in BENCH_NAMES.items():
+    fk = [k for k in fe if kname in k]
+    wk = [k for k in wr if kname in k]
+    if not fk or not wk:
+        continue
+    fv, wv = fe[fk[0]]["FETCH_SIZE"], wr[wk[0]]["WRITE_SIZE"]
+    fetch, wrt = sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024
+    traffic["kernels"][bname] = {"fetch_size_bytes_reported": round(fetch), "write_size_bytes": round(wrt),
+                                 "hbm_bytes_per_launch": round(2 * fetch + wrt), "dispatches": len(fv)}
+with open(os.path.join(os.path.dirname(os.path.abspath(dst)), "traffic.json"), "w") as f:
+    json.dump(traffic, f, indent=1)
+print(json.dumps(traffic["kernels"], indent=1))
