@@ -153,12 +153,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
     const int64_t n_wt = a.n_tiles * 8;
     const char* const masks = a.saved + (size_t)n_wt * SAVED_UNITS * 1024;
     const char* const mask_rd = lds + MASK_LDS_OFF + wave * 1024 + lane * 4;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // masks of G for the first pass go first: the ring's 8 initial copies are younger
     if ((int64_t)blockIdx.x < a.n_tiles) mask_issue(masks, (int64_t)blockIdx.x * 8 + wave, MASK_G, lds, MB_G, wave, lane);
     Ring ring;
     ring_init(ring, lds, a.packed + PACK_BWD_OFF, BWD_CHUNKS, lane, wave);
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t wt = tile * 8 + wave;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
         dr.x *= gscale; dr.y *= gscale; dr.z *= gscale; dr.w *= gscale;
 
         frag da[H_KS + 1], db[H_KS];
-        uint32_t mk[2];
+        uint32_t mk[4];       // masks are fetched ahead of their tile: four tiles can be pending
 
         // dZ10: slots 0..2 = d rgb_raw (lane half 0, elements 0..2)
 #pragma unroll
@@ -189,15 +189,15 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
         auto mask_pre = [&](auto BUF) {
             return [&](int mt) {
                 constexpr int buf = decltype(BUF)::value;
-                mk[mt & 1] = *reinterpret_cast<const uint32_t*>(mask_rd + buf * MASK_BUF_BYTES + (mt >> 1) * 256);
+                mk[mt & 3] = *reinterpret_cast<const uint32_t*>(mask_rd + buf * MASK_BUF_BYTES + (mt >> 1) * 256);
                 return zero;
             };
         };
         auto mask_epi = [&](auto DZL, frag* out) {
             return [&, out](int mt, const f32x16& acc) {
                 constexpr int dzl = decltype(DZL)::value;
-                if (mt & 1) grad_to_frags<PREC, true, 1>(acc, mk[1], out[2 * mt], out[2 * mt + 1]);
-                else grad_to_frags<PREC, true, 0>(acc, mk[0], out[2 * mt], out[2 * mt + 1]);
+                if (mt & 1) grad_to_frags<PREC, true, 1>(acc, mk[mt & 3], out[2 * mt], out[2 * mt + 1]);
+                else grad_to_frags<PREC, true, 0>(acc, mk[mt & 3], out[2 * mt], out[2 * mt + 1]);
                 store_unit_frag<PREC>(a.dz, dz_ks0(dzl), DZ_KS[dzl], n_wt, wt, 2 * mt, lane_off, out[2 * mt]);
                 store_unit_frag<PREC>(a.dz, dz_ks0(dzl), DZ_KS[dzl], n_wt, wt, 2 * mt + 1, lane_off, out[2 * mt + 1]);
             };
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
 #define NERF_IC(N) std::integral_constant<int, N>()
         // d0: dG = W_r2^T dZ10, masked by G > 0  -> dZ9 (8 k-steps) in da
         mask_landed();
+        ring_enter<0>(ring, lds);            // chunk 0 of the pass: d0 starts behind the stream's front pad
         run_layer<PREC, bwd_block0(0), 4, 1, 0, 2>(ring, lds, db, db, mask_pre(NERF_IC(MB_G)), mask_epi(NERF_IC(9), da));
         // d1: dF = W_r0[:, :256]^T dZ9 (feature_linear has no activation) -> dZ8[0..255] in db; sigma joins as k-step 16
         run_layer<PREC, bwd_block0(1), 8, G_KS, 0, 2>(ring, lds, da, da, [&](int) { return zero; },

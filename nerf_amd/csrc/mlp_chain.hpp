@@ -97,14 +97,43 @@ __device__ __forceinline__ f32x16 bias_tile(const float* bias_lds, int layer, in
     return acc;
 }
 
-// One layer: NT output tiles, each the sum over NK0 k-steps of in0 and NK1 of in1.  B0 is the
-// layer's first block in the stream; init(m) gives the starting accumulator of tile m and
-// epi(m, acc) consumes the finished tile.  A fragments are read PF blocks ahead of their MFMA,
-// never across a chunk entry (the data is only known to have landed after its barrier).
+// One layer: NT output tiles, each the sum over NK0 k-steps of in0 and NK1 of in1, consumed in the
+// stream's pair-interleaved order (stream_tile / stream_ks): two accumulators alternate, so
+// consecutive MFMAs never depend on each other.  B0 is the layer's first block in the stream;
+// init(m) gives tile m's starting accumulator (the bias) and is called INIT_AHEAD blocks before the
+// tile's first MFMA, so that its LDS reads are not waited for; epi(m, acc) consumes the finished tile.
+// A fragments are read PF blocks ahead of their MFMA, never across a chunk entry (the data is only
+// known to have landed after its barrier).
+constexpr int INIT_AHEAD = 8;
+// position of tile m's first block inside its layer
+constexpr int first_block(int NT, int NK, int m) {
+    return (m / 2) * 2 * NK + ((2 * (m / 2) + 1 < NT) ? (m & 1) : 0);
+}
 #ifndef NERF_PF
-#define NERF_PF 3
+#define NERF_PF 4
 #endif
 constexpr int PF = NERF_PF;
+
+// The A-fragment reads and their waits are written as inline asm.  Left to the compiler, the reads get
+// moved next to their use and every group of MFMAs is preceded by `s_waitcnt lgkmcnt(0)`, which waits
+// for the read issued just before it: the LDS latency is then exposed every few MFMAs.  Here block
+// i+PF is requested, then `lgkmcnt(n)` lets the n newest requests stay in flight, then MFMA i runs.
+// LDS operations return in order, so LDS reads the compiler issues in between (bias rows, masks) only
+// make these waits, and the compiler's own, wait for more than they need.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ i32x4 lds_read_b128(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit immediate");
+    i32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// wait until at most N LDS operations are outstanding; ties `v` so that its use stays behind the wait
+template <int N>
+__device__ __forceinline__ void lds_wait(i32x4& v) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
 // last block (layer-relative) that may have been requested once step i runs: i+PF, clipped to the
 // layer and to the chunk that block i lives in
 constexpr int pf_hi(int B0, int NB, int i) {
@@ -120,10 +149,52 @@ constexpr int pf_lo(int B0, int NB, int i) {
 }
 
 // tile epilogues of this layer that ran during the CHUNK_BLOCKS blocks before block i
-constexpr int tiles_ended_before(int NK, int i) {
+constexpr int tiles_ended_before(int NT, int NK, int i) {
     int n = 0;
-    for (int j = (i > CHUNK_BLOCKS ? i - CHUNK_BLOCKS : 0); j < i; ++j) n += (j % NK == NK - 1);
+    for (int j = (i > CHUNK_BLOCKS ? i - CHUNK_BLOCKS : 0); j < i; ++j) n += (stream_ks(NT, NK, j) == NK - 1);
     return n;
+}
+
+// Block k2's request / block i's wait with compile-time offsets and counts.  The loop that calls
+// these is fully unrolled, but `i` is still a variable in the source, so the immediates are picked
+// by a switch that folds to one case.
+template <int OFF0>
+__device__ __forceinline__ i32x4 read_block_sw(uint32_t addr, int blk) {
+    switch (blk) {
+#define NERF_CASE(B) case B: return lds_read_b128<OFF0 + (B) * BLOCK_BYTES>(addr);
+        NERF_CASE(0) NERF_CASE(1) NERF_CASE(2) NERF_CASE(3) NERF_CASE(4) NERF_CASE(5) NERF_CASE(6) NERF_CASE(7)
+        NERF_CASE(8) NERF_CASE(9) NERF_CASE(10) NERF_CASE(11) NERF_CASE(12) NERF_CASE(13) NERF_CASE(14) NERF_CASE(15)
+        NERF_CASE(16) NERF_CASE(17) NERF_CASE(18) NERF_CASE(19) NERF_CASE(20) NERF_CASE(21) NERF_CASE(22) NERF_CASE(23)
+        NERF_CASE(24) NERF_CASE(25) NERF_CASE(26) NERF_CASE(27) NERF_CASE(28) NERF_CASE(29) NERF_CASE(30)
+#undef NERF_CASE
+        default: return lds_read_b128<OFF0 + 31 * BLOCK_BYTES>(addr);
+    }
+}
+__device__ __forceinline__ void wait_sw(i32x4& v, int n) {
+    switch (n) {
+        case 0: lds_wait<0>(v); break;
+        case 1: lds_wait<1>(v); break;
+        case 2: lds_wait<2>(v); break;
+        case 3: lds_wait<3>(v); break;
+        case 4: lds_wait<4>(v); break;
+        case 5: lds_wait<5>(v); break;
+        case 6: lds_wait<6>(v); break;
+        case 7: lds_wait<7>(v); break;
+        default: lds_wait<8>(v); break;
+    }
+}
+template <int B0, int NB, class Z>
+__device__ __forceinline__ void request_blocks(uint32_t rd_base, i32x4* a, Z, int i) {
+    const int lo = pf_lo(B0, NB, i), hi = pf_hi(B0, NB, i);
+#pragma unroll
+    for (int d = 0; d <= PF; ++d) {
+        const int k2 = lo + d;
+        if (k2 <= hi) a[k2] = read_block_sw<0>(rd_base, (B0 + k2) % CHUNK_BLOCKS);
+    }
+}
+template <int B0, int NB>
+__device__ __forceinline__ void wait_block(i32x4* a, int i) {
+    wait_sw(a[i], pf_hi(B0, NB, i) - i);      // requests younger than block i's
 }
 
 // VM_PER_TILE: VMEM operations every tile epilogue of this layer is known to issue (0 if unknown).
@@ -132,34 +203,32 @@ __device__ __forceinline__ void run_layer(Ring& ring, char* lds, const typename 
                                           const typename Prec<PREC>::frag* in1, Init&& init, Epi&& epi) {
     typedef typename Prec<PREC>::frag frag;
     constexpr int NK = NK0 + NK1, NB = NT * NK;
-    frag a[NB];
-    f32x16 acc = init(0);
-    f32x16 acc_next = acc;
+    i32x4 a[NB];
+    f32x16 acc[2], start[2];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int m = i / NK, ks = i % NK;
+        const int m = stream_tile(NT, NK, i), ks = stream_ks(NT, NK, i);
         const int b = B0 + i;
         if (b % CHUNK_BLOCKS == 0) {
             // folds to one call once the loop is unrolled
-            const int younger = VM_PER_TILE * tiles_ended_before(NK, i);
+            const int younger = VM_PER_TILE * tiles_ended_before(NT, NK, i);
             if (younger >= 8) ring_enter<8>(ring, lds);
             else if (younger >= 4) ring_enter<4>(ring, lds);
             else if (younger >= 2) ring_enter<2>(ring, lds);
             else ring_enter<0>(ring, lds);
         }
-        const int lo = pf_lo(B0, NB, i), hi = pf_hi(B0, NB, i);
+        request_blocks<B0, NB>(ring.rd_base, a, std::integral_constant<int, 0>(), i);
 #pragma unroll
-        for (int d = 0; d <= PF; ++d) {
-            const int k2 = lo + d;
-            if (k2 <= hi)
-                a[k2] = *reinterpret_cast<const frag*>(lds + ring.rd_base + ((B0 + k2) % CHUNK_BLOCKS) * BLOCK_BYTES);
+        for (int t = 0; t < NT; ++t) {
+            // not before the previous tile of the same parity (2*NK blocks earlier) has taken its own
+            const int ahead = INIT_AHEAD < 2 * NK - 1 ? INIT_AHEAD : 2 * NK - 1;
+            const int f = first_block(NT, NK, t);
+            if ((f - ahead > 0 ? f - ahead : 0) == i) start[t & 1] = init(t);
         }
-        if (ks == 0 && m + 1 < NT) acc_next = init(m + 1);
-        acc = Prec<PREC>::mfma(a[i], ks < NK0 ? in0[ks] : in1[ks - NK0], acc);
-        if (ks == NK - 1) {
-            epi(m, acc);
-            acc = acc_next;
-        }
+        wait_block<B0, NB>(a, i);
+        acc[m & 1] = Prec<PREC>::mfma(__builtin_bit_cast(frag, a[i]), ks < NK0 ? in0[ks] : in1[ks - NK0],
+                                      ks == 0 ? start[m & 1] : acc[m & 1]);
+        if (ks == NK - 1) epi(m, acc[m & 1]);
     }
 }
 

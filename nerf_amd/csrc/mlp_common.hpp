@@ -66,18 +66,39 @@ constexpr int OFF_WR2 = OFF_BR0 + 128;          constexpr int OFF_BR2 = OFF_WR2 
 constexpr int N_PARAMS = OFF_BR2 + 3;
 static_assert(N_PARAMS == NERF_MLP_NPARAMS, "parameter count");
 
+// ---- order of a layer's blocks in a stream ---------------------------------------------------------
+// A wave that feeds one accumulator tile with dependent MFMAs back to back leaves the matrix pipe idle
+// between them (two waves per SIMD do not cover the dependent-issue latency: a bare single-chain loop
+// reaches about 1.3 PFLOP/s, two chains 1.8).  Output tiles are therefore taken two at a time and their
+// k-steps interleaved: (tile 2p, ks 0), (tile 2p+1, ks 0), (2p, 1), (2p+1, 1), ...  An odd last tile
+// runs alone.  i is the block's position inside the layer, NT x NK the layer's tiles and k-steps.
+__host__ __device__ constexpr int stream_tile(int NT, int NK, int i) {
+    const int p = i / (2 * NK), r = i - p * 2 * NK;
+    return (2 * p + 1 < NT) ? 2 * p + (r & 1) : 2 * p;
+}
+__host__ __device__ constexpr int stream_ks(int NT, int NK, int i) {
+    const int p = i / (2 * NK), r = i - p * 2 * NK;
+    return (2 * p + 1 < NT) ? (r >> 1) : r;
+}
+
 // ---- forward stream: blocks per layer = out_tiles * k_steps ------------------------------
 //                                   L0  L1   L2   L3   L4   L5   L6   L7   L8   L9  L10
 constexpr int FWD_TILES[NLAYERS] = {  8,  8,   8,   8,   8,   8,   8,   8,   9,   4,   1};
 constexpr int FWD_KS[NLAYERS]    = {  4, 16,  16,  16,  16,  20,  16,  16,  16,  18,   8};
+// The stream starts with FWD_PAD zero blocks that are never read: they shift the layers so that a tile
+// pair of a 16-k-step layer (32 blocks) ends in the middle of a 32-block chunk instead of at its end.
+// A pair's epilogue (bias, ReLU, conversion: vector ALU work) can then be overlapped with the next
+// pair's MFMAs; at a chunk end it would sit in front of the chunk-entry barrier with nothing to overlap.
+constexpr int FWD_PAD = 16;
 constexpr int fwd_block0(int layer) {
-    int b = 0;
+    int b = FWD_PAD;
     for (int l = 0; l < layer; ++l) b += FWD_TILES[l] * FWD_KS[l];
     return b;
 }
-constexpr int FWD_BLOCKS = fwd_block0(NLAYERS);
-static_assert(FWD_BLOCKS == 1184 && FWD_BLOCKS % CHUNK_BLOCKS == 0, "forward stream");
-constexpr int FWD_CHUNKS = FWD_BLOCKS / CHUNK_BLOCKS;   // 37
+constexpr int FWD_BLOCKS_REAL = fwd_block0(NLAYERS);     // 1200
+constexpr int FWD_CHUNKS = (FWD_BLOCKS_REAL + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;   // 38
+constexpr int FWD_BLOCKS = FWD_CHUNKS * CHUNK_BLOCKS;    // 1216 (pad and tail blocks are zero, never read)
+static_assert(FWD_BLOCKS_REAL == 1200 && FWD_PAD % 4 == 0, "forward stream");
 
 // ---- backward (dgrad) stream, consumption order L10, L9, L8, L7, ..., L1 --------------------
 // index d = 0..9 for layers 10, 9, ..., 1 (L0 needs no input gradient)
@@ -88,15 +109,16 @@ constexpr int FWD_CHUNKS = FWD_BLOCKS / CHUNK_BLOCKS;   // 37
 constexpr int NBWD = 10;
 constexpr int BWD_TILES[NBWD] = {4, 8, 8, 8, 8, 8, 8, 8, 8, 8};
 constexpr int BWD_KS[NBWD]    = {1, 8, 17, 16, 16, 16, 16, 16, 16, 16};
+constexpr int BWD_PAD = 4;       // as FWD_PAD: puts the pair ends of d3..d9 at block 16 of their chunk
 constexpr int bwd_block0(int d) {
-    int b = 0;
+    int b = BWD_PAD;
     for (int i = 0; i < d; ++i) b += BWD_TILES[i] * BWD_KS[i];
     return b;
 }
-constexpr int BWD_BLOCKS_REAL = bwd_block0(NBWD);        // 1100
+constexpr int BWD_BLOCKS_REAL = bwd_block0(NBWD);        // 1104
 constexpr int BWD_CHUNKS = (BWD_BLOCKS_REAL + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;   // 35
-constexpr int BWD_BLOCKS = BWD_CHUNKS * CHUNK_BLOCKS;   // 1120 (tail blocks are zero, never read)
-static_assert(BWD_BLOCKS_REAL == 1100, "backward stream");
+constexpr int BWD_BLOCKS = BWD_CHUNKS * CHUNK_BLOCKS;   // 1120 (pad and tail blocks are zero, never read)
+static_assert(BWD_BLOCKS_REAL == 1104 && bwd_block0(3) % CHUNK_BLOCKS == 16, "backward stream");
 
 // ---- bias table (fp32), one padded row per forward layer ------------------------------------
 constexpr int BIAS_STRIDE = 288;                         // L8 has 257 real rows

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
         };
 #define NERF_BIAS(LAYER) [&](int mt) { return bias_tile(bias_lds, LAYER, mt, h); }
 #define NERF_IC(N) std::integral_constant<int, N>()
+        ring_enter<0>(ring, lds);            // chunk 0 of the pass: L0 starts behind the stream's front pad
         run_layer<PREC, fwd_block0(0), 8, PE_KS, 0, SV>(ring, lds, pe, pe, NERF_BIAS(0), hidden(NERF_IC(0), ha));
         run_layer<PREC, fwd_block0(1), 8, H_KS, 0, SV>(ring, lds, ha, ha, NERF_BIAS(1), hidden(NERF_IC(1), hb));
         run_layer<PREC, fwd_block0(2), 8, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(2), hidden(NERF_IC(2), ha));

@@ -78,20 +78,25 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
         if (e < NF) {
             int b = (int)(e >> 9);
             const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
-            int L = 0;
-            while (L + 1 < NLAYERS && b >= FWD_TILES[L] * FWD_KS[L]) { b -= FWD_TILES[L] * FWD_KS[L]; ++L; }
-            const int m = b / FWD_KS[L], ks = b - m * FWD_KS[L];
-            const float v = fwd_weight(P, L, 32 * m + (lane & 31), ks, slot_of(ks, lane >> 5, j));
+            float v = 0.0f;
+            if (b >= FWD_PAD && b < FWD_BLOCKS_REAL) {
+                b -= FWD_PAD;
+                int L = 0;
+                while (L + 1 < NLAYERS && b >= FWD_TILES[L] * FWD_KS[L]) { b -= FWD_TILES[L] * FWD_KS[L]; ++L; }
+                const int m = stream_tile(FWD_TILES[L], FWD_KS[L], b), ks = stream_ks(FWD_TILES[L], FWD_KS[L], b);
+                v = fwd_weight(P, L, 32 * m + (lane & 31), ks, slot_of(ks, lane >> 5, j));
+            }
             fwd[e] = (T)v;
         } else if (e < NF + NB) {
             const int64_t eb = e - NF;
             int b = (int)(eb >> 9);
             const int lane = (int)(eb >> 3) & 63, j = (int)eb & 7;
             float v = 0.0f;
-            if (b < BWD_BLOCKS_REAL) {
+            if (b >= BWD_PAD && b < BWD_BLOCKS_REAL) {
+                b -= BWD_PAD;
                 int d = 0;
                 while (d + 1 < NBWD && b >= BWD_TILES[d] * BWD_KS[d]) { b -= BWD_TILES[d] * BWD_KS[d]; ++d; }
-                const int m = b / BWD_KS[d], ks = b - m * BWD_KS[d];
+                const int m = stream_tile(BWD_TILES[d], BWD_KS[d], b), ks = stream_ks(BWD_TILES[d], BWD_KS[d], b);
                 v = bwd_weight(P, d, 32 * m + (lane & 31), slot_of(ks, lane >> 5, j));
             }
             bwd[eb] = (T)v;

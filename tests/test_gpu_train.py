@@ -6,7 +6,7 @@ so every hidden unit whose fp32 pre-activation is smaller than the 16-bit forwar
 may flip, and a flipped unit changes the gradient by its whole contribution: with a share p of
 flipped units the gradient differs from the fp32 reference by about sqrt(p) in relative norm
 (5-10 % for bf16, 2-4 % for fp16 at random init), whatever the kernel does.  The kernels are
-therefore checked tightly (2 %) against the oracle evaluated with the same operand rounding
+therefore checked tightly (2 % bf16, 1.5 % fp16) against the oracle evaluated with the same operand rounding
 (weights and layer inputs rounded to the operand type, fp32 accumulation: identical masks), and
 loosely against the plain fp32 oracle / golden vectors.
 """
@@ -77,7 +77,7 @@ def test_mlp_gradients(amd, golden, precision, P):
     (raw.view(-1, 4) * cot.to(DEV)).sum().backward()
     # forward against the emulated oracle: only accumulation order and the in-kernel sin/cos differ
     assert maxabs(raw.view(-1, 4), raw_e) < (1e-3 if precision == "bf16" else 1.5e-4)
-    tight = 2e-2 if precision == "bf16" else 1e-2
+    tight = 2e-2 if precision == "bf16" else 1.5e-2
     loose = 0.2 if precision == "bf16" else 0.08
     for k, p in m.named_parameters():
         assert p.grad is not None and p.grad.shape == p.shape
