@@ -124,11 +124,45 @@ static_assert(BWD_BLOCKS_REAL == 1104 && bwd_block0(3) % CHUNK_BLOCKS == 16, "ba
 constexpr int BIAS_STRIDE = 288;                         // L8 has 257 real rows
 constexpr int BIAS_FLOATS = NLAYERS * BIAS_STRIDE;       // 3168 floats = 12672 B
 
+// ---- inference stream: the same network tiled for v_mfma_f32_16x16x32 ------------------------------
+// The inference forward (nothing saved) uses the 16x16x32 shape: A = 16 output rows x 32 inputs, B = 32
+// inputs x 16 samples, and a wave's 32 samples are two column tiles that share every A block.  On this
+// chip that shape sustains a higher clock than 32x32x16 at equal work (measured with bare loops on
+// random data: 1.76 vs 1.5 PFLOP/s with one LDS block per 32 cycles of MFMA).  Lane l = (n = l&15,
+// g = l>>4).  C/D: column n, rows 4g..4g+3.  Fragment element j of k-step ks in lane group g is slot
+//        slot16(ks, g, j) = 32*ks + 16*(j>>2) + 4*g + (j&3)
+// so row tile rt of one layer lands in elements 4*(rt&1) .. +3 of k-step rt>>1 of the next.  Block
+// (layer, row tile rt, k-step ks): lane l, element j = W[16 rt + (l&15)][feature of slot16(ks, l>>4, j)].
+//                                      L0  L1  L2  L3  L4  L5  L6  L7  L8  L9 L10
+constexpr int F16_TILES[NLAYERS] = {   16, 16, 16, 16, 16, 16, 16, 16, 17,  8,  1};
+constexpr int F16_KS[NLAYERS]    = {    2,  8,  8,  8,  8, 10,  8,  8,  8,  9,  4};
+constexpr int F16_PAD = 8;       // front pad: pair ends (16 blocks apart) fall at blocks 8 and 24 of a chunk
+constexpr int f16_block0(int layer) {
+    int b = F16_PAD;
+    for (int l = 0; l < layer; ++l) b += F16_TILES[l] * F16_KS[l];
+    return b;
+}
+constexpr int F16_BLOCKS_REAL = f16_block0(NLAYERS);     // 1180
+constexpr int F16_CHUNKS = (F16_BLOCKS_REAL + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;   // 37
+constexpr int F16_BLOCKS = F16_CHUNKS * CHUNK_BLOCKS;
+static_assert(F16_BLOCKS_REAL == 1180, "inference stream");
+__host__ __device__ constexpr int slot16(int ks, int g, int j) { return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3); }
+// Positional-encoding inputs of that layout: lane group g evaluates sines (g even) or cosines (g odd) of
+// the lower (g < 2) or upper half of the L frequencies, 3*L/2 values, then one raw coordinate
+// (g = 0, 1, 2 -> x, y, z).  q = 8*ks + j enumerates a lane's values; returns the reference feature or -1.
+__host__ __device__ constexpr int pe16_feature(int L, int g, int q) {
+    const int FH = L / 2, NQ = 3 * FH;
+    if (q < NQ) return 3 + 6 * (FH * (g >> 1) + q / 3) + 3 * (g & 1) + q % 3;
+    if (q == NQ) return g < 3 ? g : -1;
+    return -1;
+}
+
 // ---- packed buffer layout ----------------------------------------------------------------------
 constexpr int64_t PACK_FWD_OFF = 0;
 constexpr int64_t PACK_BWD_OFF = PACK_FWD_OFF + (int64_t)FWD_BLOCKS * BLOCK_BYTES;
 constexpr int64_t PACK_BIAS_OFF = PACK_BWD_OFF + (int64_t)BWD_BLOCKS * BLOCK_BYTES;
-constexpr int64_t PACK_BYTES = PACK_BIAS_OFF + (int64_t)BIAS_FLOATS * 4;
+constexpr int64_t PACK_F16_OFF = (PACK_BIAS_OFF + (int64_t)BIAS_FLOATS * 4 + 1023) / 1024 * 1024;
+constexpr int64_t PACK_BYTES = PACK_F16_OFF + (int64_t)F16_BLOCKS * BLOCK_BYTES;
 
 // ---- slot maps --------------------------------------------------------------------------------
 __host__ __device__ constexpr int slot_of(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
@@ -193,12 +227,18 @@ template <> struct Prec<NERF_PREC_BF16> {
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
 };
 template <> struct Prec<NERF_PREC_FP16> {
     typedef _Float16 elem;
     typedef _Float16 frag __attribute__((ext_vector_type(8)));
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 };
 

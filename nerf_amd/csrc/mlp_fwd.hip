@@ -260,11 +260,17 @@ static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* strea
     return nerf_launch_status();
 }
 
+// inference (nothing saved) runs on the 16x16x32 kernel of mlp_fwd16.hip
+int nerf_mlp_fwd16_launch(int64_t n_rays, int S, const float* rays_o, const float* rays_d, const float* z,
+                          const void* packed, int precision, float* raw, void* stream);
+
 extern "C" int nerf_mlp_fwd(int64_t n_rays, int S, const float* rays_o, const float* rays_d, const float* z,
                             const void* packed, int precision, float* raw, void* saved, void* stream) {
     NERF_REQUIRE(rays_o && rays_d && z && packed && raw, NERF_E_NULL);
     NERF_REQUIRE(n_rays >= 0 && S >= 1, NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    if (saved == nullptr) return nerf_mlp_fwd16_launch(n_rays, S, rays_o, rays_d, z, packed, precision, raw, stream);
     FwdArgs a{};
     a.M = n_rays * S; a.n_tiles = (a.M + TILE_SAMPLES - 1) / TILE_SAMPLES; a.S = S;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.packed = (const char*)packed; a.raw = raw;

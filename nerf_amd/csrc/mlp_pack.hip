@@ -37,6 +37,41 @@ __device__ __forceinline__ float fwd_weight(const float* __restrict__ P, int L, 
     }
 }
 
+// inference stream: weight of output `row` and the input feature that slot16 / pe16_feature assign to
+// (k-step ks, lane group g, element j)
+__device__ __forceinline__ float f16_weight(const float* __restrict__ P, int L, int row, int ks, int g, int j) {
+    const int slot = slot16(ks, g, j);
+    const int q = 8 * ks + j;
+    switch (L) {
+        case 0: {
+            const int f = pe16_feature(10, g, q);
+            return f >= 0 ? P[OFF_W0 + row * 63 + f] : 0.0f;
+        }
+        case 1: return P[OFF_W1 + row * 256 + slot];
+        case 2: return P[OFF_W2 + row * 256 + slot];
+        case 3: return P[OFF_W3 + row * 256 + slot];
+        case 4: return P[OFF_W4 + row * 256 + slot];
+        case 5: {
+            if (ks < 2) {
+                const int f = pe16_feature(10, g, q);
+                return f >= 0 ? P[OFF_W5 + row * 319 + f] : 0.0f;
+            }
+            return P[OFF_W5 + row * 319 + 63 + (slot - 64)];
+        }
+        case 6: return P[OFF_W6 + row * 256 + slot];
+        case 7: return P[OFF_W7 + row * 256 + slot];
+        case 8:
+            if (row < 256) return P[OFF_WF + row * 256 + slot];
+            return row == 256 ? P[OFF_WS + slot] : 0.0f;
+        case 9: {
+            if (ks < 8) return P[OFF_WR0 + row * 283 + slot];
+            const int f = pe16_feature(4, g, j);
+            return f >= 0 ? P[OFF_WR0 + row * 283 + 256 + f] : 0.0f;
+        }
+        default: return row < 3 ? P[OFF_WR2 + row * 128 + slot] : 0.0f;
+    }
+}
+
 // A = W^T: row = input feature, k = output slot
 __device__ __forceinline__ float bwd_weight(const float* __restrict__ P, int d, int rin, int k) {
     switch (d) {
@@ -70,9 +105,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
     typedef typename Prec<PREC>::elem T;
     T* fwd = reinterpret_cast<T*>(out + PACK_FWD_OFF);
     T* bwd = reinterpret_cast<T*>(out + PACK_BWD_OFF);
+    T* f16 = reinterpret_cast<T*>(out + PACK_F16_OFF);
     float* bias = reinterpret_cast<float*>(out + PACK_BIAS_OFF);
-    constexpr int64_t NF = (int64_t)FWD_BLOCKS * 512, NB = (int64_t)BWD_BLOCKS * 512;
-    const int64_t total = NF + NB + BIAS_FLOATS;
+    constexpr int64_t NF = (int64_t)FWD_BLOCKS * 512, NB = (int64_t)BWD_BLOCKS * 512, N16 = (int64_t)F16_BLOCKS * 512;
+    const int64_t total = NF + NB + BIAS_FLOATS + N16;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         if (e < NF) {
@@ -100,9 +136,24 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
                 v = bwd_weight(P, d, 32 * m + (lane & 31), slot_of(ks, lane >> 5, j));
             }
             bwd[eb] = (T)v;
-        } else {
+        } else if (e < NF + NB + BIAS_FLOATS) {
             const int i = (int)(e - NF - NB);
             bias[i] = bias_value(P, i / BIAS_STRIDE, i % BIAS_STRIDE);
+        } else {
+            const int64_t ef = e - NF - NB - BIAS_FLOATS;
+            int b = (int)(ef >> 9);
+            const int lane = (int)(ef >> 3) & 63, j = (int)ef & 7;
+            float v = 0.0f;
+            if (b >= F16_PAD && b < F16_BLOCKS_REAL) {
+                b -= F16_PAD;
+                int L = 0;
+                while (L + 1 < NLAYERS && b >= F16_TILES[L] * F16_KS[L]) { b -= F16_TILES[L] * F16_KS[L]; ++L; }
+                const int rt = stream_tile(F16_TILES[L], F16_KS[L], b), ks = stream_ks(F16_TILES[L], F16_KS[L], b);
+                const int row = 16 * rt + (lane & 15);
+                const int rows = L < 8 ? 256 : (L == 8 ? 257 : (L == 9 ? 128 : 3));
+                if (row < rows) v = f16_weight(P, L, row, ks, lane >> 4, j);
+            }
+            f16[ef] = (T)v;
         }
     }
 }
