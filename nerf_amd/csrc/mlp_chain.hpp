@@ -33,6 +33,7 @@ struct Ring {
     uint32_t rd_base;       // LDS address the current chunk is read from: slot*CHUNK_BYTES + lane*16
     uint32_t stream_bytes;  // n_chunks * CHUNK_BYTES
     int slot;               // ring slot of the current chunk
+    int extra_enters;       // chunk entries that still have to leave a batch of side copies in flight
 };
 
 // Issue this wave's 4 KiB share of the chunk at stream offset `off` into ring slot `slot`.  One
@@ -52,6 +53,7 @@ __device__ __forceinline__ void ring_init(Ring& r, char* lds, const void* stream
     r.wave_off = wave * (CHUNK_BYTES / 8);
     r.lane16 = lane * 16;
     r.slot = RING_SLOTS - 1;          // first enter() moves to slot 0
+    r.extra_enters = 0;
     r.rd_base = LDS_RING_OFF;
     r.stream_bytes = n_chunks * CHUNK_BYTES;
     ring_issue(r, lds, r.wave_off, 0);
@@ -66,10 +68,18 @@ __device__ __forceinline__ void ring_init(Ring& r, char* lds, const void* stream
 //    reading the previous chunk, whose slot is the one refilled next.
 //  - YOUNGER: a lower bound on the VMEM operations (stores of saved tensors) this wave issued after
 //    its newest chunk of DMA; they complete after it, so they may stay in flight as well.
-template <int YOUNGER = 0>
+//  - SIDE: a kernel that issues a batch of SIDE further LDS-DMA copies right after a chunk entry (inputs
+//    of its next pass) sets r.extra_enters = 2: at the next two entries the batch is younger than the
+//    chunk waited for and may stay in flight; from the third entry on it is older and has landed.
+template <int YOUNGER = 0, int SIDE = 0>
 __device__ __forceinline__ void ring_enter(Ring& r, char* lds) {
-    static_assert(DMA_PER_CHUNK + YOUNGER <= 63, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK + YOUNGER) : "memory");
+    static_assert(DMA_PER_CHUNK + YOUNGER + SIDE <= 63, "vmcnt is a 6-bit counter");
+    if (SIDE > 0 && r.extra_enters > 0) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK + YOUNGER + SIDE) : "memory");
+        --r.extra_enters;
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK + YOUNGER) : "memory");
+    }
 #ifndef NERF_ABL_NO_BARRIER          // timing experiment only: results are wrong without the barrier
     __builtin_amdgcn_s_barrier();
 #endif

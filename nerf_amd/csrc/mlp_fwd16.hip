@@ -61,6 +61,14 @@ __device__ __forceinline__ void encode16(float px, float py, float pz, int g, ty
     }
 }
 
+// Inputs of the next pass travel global -> LDS by DMA while the current pass computes: per column tile
+// z and the ray's origin and direction, one dword per lane each (IN_COPIES copies per wave and pass into
+// a per-wave area behind the ring).
+constexpr int IN_COPIES = 14;
+constexpr int IN_LDS_OFF = CHAIN_LDS_BYTES;
+constexpr int IN_WAVE_BYTES = IN_COPIES * 256;
+constexpr int FWD16_LDS_BYTES = CHAIN_LDS_BYTES + 8 * IN_WAVE_BYTES;
+
 // One layer on the narrow shape.  in0 / in1: fragments [k-step][column tile]; init(rt) gives the four
 // bias values of this lane's rows of row tile rt; epi(rt, acc0, acc1) consumes the finished tile pair
 // (one accumulator per column tile).  Chunk entries, A-block requests and waits as in run_layer.
@@ -74,7 +82,7 @@ __device__ __forceinline__ void run_layer16(Ring& ring, char* lds, const typenam
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int rt = stream_tile(NT, NK, i), ks = stream_ks(NT, NK, i);
-        if ((B0 + i) % CHUNK_BLOCKS == 0) ring_enter<0>(ring, lds);
+        if ((B0 + i) % CHUNK_BLOCKS == 0) ring_enter<0, IN_COPIES>(ring, lds);
         request_blocks<B0, NB>(ring.rd_base, a, std::integral_constant<int, 0>(), i);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -102,7 +110,7 @@ __device__ __forceinline__ void tile16_to_frag(const f32x4& acc, int rt, typenam
 template <int PREC>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16Args a) {
     typedef typename Prec<PREC>::frag frag;
-    __shared__ __attribute__((aligned(16))) char lds[CHAIN_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[FWD16_LDS_BYTES];
     float* bias_lds = reinterpret_cast<float*>(lds + LDS_BIAS_OFF);
 
     const int lane = threadIdx.x & 63;
@@ -118,29 +126,63 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
     Ring ring;
     ring_init(ring, lds, a.packed + PACK_F16_OFF, F16_CHUNKS, lane, wave);
 
-    for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    // Inputs of a pass.  issue_inputs() starts the copies (it must directly follow a chunk entry, see
+    // ring_enter's SIDE); read_inputs() turns what has landed into points and unit view directions.
+    const int in_base = IN_LDS_OFF + wave * IN_WAVE_BYTES;
+    auto issue_inputs = [&](int64_t tile) {
         const int64_t wt = tile * 8 + wave;
-        frag pe[2][2], vpe[1][2];
-        bool valid[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const int64_t m = wt * WAVE_SAMPLES + 16 * ct + n;
-            valid[ct] = m < a.M;
-            float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
-            if (valid[ct]) {
-                const int64_t ray = m / a.S;
-                const float zz = a.z[m];
-                const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
-                const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-                px = __fadd_rn(ox, __fmul_rn(dx, zz));        // nerf.py:409
-                py = __fadd_rn(oy, __fmul_rn(dy, zz));
-                pz = __fadd_rn(oz, __fmul_rn(dz, zz));
-                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-                vx = dx / nrm; vy = dy / nrm; vz = dz / nrm;  // nerf.py:417
-            }
-            encode16<PREC, 10, 2>(px, py, pz, g, &pe[0][ct], 2);
-            encode16<PREC, 4, 1>(vx, vy, vz, g, &vpe[0][ct], 2);
+            int64_t m = wt * WAVE_SAMPLES + 16 * ct + n;
+            if (m >= a.M) m = a.M - 1;                        // lanes past the end copy a valid sample
+            const int64_t ray = m / a.S;
+            lds_char* l = (lds_char*)(lds + in_base + ct * 7 * 256);
+            __builtin_amdgcn_global_load_lds((gbl_char*)(a.z + m), l, 4, 0, 0);
+            const float* o = a.rays_o + 3 * ray;
+            const float* d = a.rays_d + 3 * ray;
+            // the instruction offset moves the LDS destination and the global source alike
+            __builtin_amdgcn_global_load_lds((gbl_char*)(o + 0) - 1 * 256, l, 4, 1 * 256, 0);
+            __builtin_amdgcn_global_load_lds((gbl_char*)(o + 1) - 2 * 256, l, 4, 2 * 256, 0);
+            __builtin_amdgcn_global_load_lds((gbl_char*)(o + 2) - 3 * 256, l, 4, 3 * 256, 0);
+            __builtin_amdgcn_global_load_lds((gbl_char*)(d + 0) - 4 * 256, l, 4, 4 * 256, 0);
+            __builtin_amdgcn_global_load_lds((gbl_char*)(d + 1) - 5 * 256, l, 4, 5 * 256, 0);
+            __builtin_amdgcn_global_load_lds((gbl_char*)(d + 2) - 6 * 256, l, 4, 6 * 256, 0);
         }
+    };
+    // what has landed -> fragments of the point encoding / of the view-direction encoding.  The
+    // directions stay in LDS until the next issue_inputs(), so nothing is carried in registers.
+    auto point_encoding = [&](frag (*pe)[2]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float* f = reinterpret_cast<const float*>(lds + in_base + ct * 7 * 256) + lane;
+            const float zz = f[0], ox = f[64], oy = f[128], oz = f[192], dx = f[256], dy = f[320], dz = f[384];
+            encode16<PREC, 10, 2>(__fadd_rn(ox, __fmul_rn(dx, zz)), __fadd_rn(oy, __fmul_rn(dy, zz)),
+                                  __fadd_rn(oz, __fmul_rn(dz, zz)), g, &pe[0][ct], 2);      // nerf.py:409
+        }
+    };
+    auto view_encoding = [&](frag (*vpe)[2]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float* f = reinterpret_cast<const float*>(lds + in_base + ct * 7 * 256) + lane;
+            const float dx = f[256], dy = f[320], dz = f[384];
+            const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+            encode16<PREC, 4, 1>(dx / nrm, dy / nrm, dz / nrm, g, &vpe[0][ct], 2);          // nerf.py:417
+        }
+    };
+
+    frag pe[2][2];
+    if ((int64_t)blockIdx.x < a.n_tiles) {
+        issue_inputs(blockIdx.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first pass only: nothing to overlap with yet
+        point_encoding(pe);
+    }
+
+    for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t wt = tile * 8 + wave;
+        const bool has_next = tile + gridDim.x < a.n_tiles;
+        frag vpe[1][2];
+        view_encoding(vpe);
+        const bool valid0 = wt * WAVE_SAMPLES + n < a.M, valid1 = wt * WAVE_SAMPLES + 16 + n < a.M;
 
         frag ha[8][2], hb[8][2];
         auto bias = [&](int layer) {
@@ -154,7 +196,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
                 tile16_to_frag<PREC, true>(c1, rt, out[rt >> 1][1]);
             };
         };
-        ring_enter<0>(ring, lds);            // chunk 0 of the pass: L0 starts behind the stream's front pad
+        ring_enter<0, IN_COPIES>(ring, lds); // chunk 0 of the pass: L0 starts behind the stream's front pad
         run_layer16<PREC, f16_block0(0), 16, 2, 0>(ring, lds, pe, pe, bias(0), hidden(ha));
         run_layer16<PREC, f16_block0(1), 16, 8, 0>(ring, lds, ha, ha, bias(1), hidden(hb));
         run_layer16<PREC, f16_block0(2), 16, 8, 0>(ring, lds, hb, hb, bias(2), hidden(ha));
@@ -162,6 +204,8 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
         run_layer16<PREC, f16_block0(4), 16, 8, 0>(ring, lds, hb, hb, bias(4), hidden(ha));
         run_layer16<PREC, f16_block0(5), 16, 2, 8>(ring, lds, pe, ha, bias(5), hidden(hb));
         run_layer16<PREC, f16_block0(6), 16, 8, 0>(ring, lds, hb, hb, bias(6), hidden(ha));
+        static_assert(f16_block0(7) % CHUNK_BLOCKS == 8, "the copies below assume at most 8 blocks since the last chunk entry");
+        if (has_next) { issue_inputs(tile + gridDim.x); ring.extra_enters = 2; }   // land during L7 and L8
         run_layer16<PREC, f16_block0(7), 16, 8, 0>(ring, lds, ha, ha, bias(7), hidden(hb));
 
         // L8: feature_linear (no activation) -> ha, sigma_linear -> row 0 of row tile 16 (lane group 0)
@@ -175,6 +219,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
                 sigma[0] = c0[0]; sigma[1] = c1[0];
             }
         });
+        if (has_next) point_encoding(pe);                 // its registers are free again after L5
         // L9: rgb_layers.0 on [feature, view encoding] -> relu -> G (first 4 k-steps of hb)
         run_layer16<PREC, f16_block0(9), 8, 8, 1>(ring, lds, ha, vpe, bias(9), hidden(hb));
         // L10: rgb_layers.2 -> rows 0..2 (lane group 0); (rgb_raw, sigma_raw) per sample
@@ -182,8 +227,8 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
                                                    [&](int, const f32x4& c0, const f32x4& c1) {
             if (g == 0) {
                 const int64_t m0 = wt * WAVE_SAMPLES + n;
-                if (valid[0]) reinterpret_cast<float4*>(a.raw)[m0] = make_float4(c0[0], c0[1], c0[2], sigma[0]);
-                if (valid[1]) reinterpret_cast<float4*>(a.raw)[m0 + 16] = make_float4(c1[0], c1[1], c1[2], sigma[1]);
+                if (valid0) reinterpret_cast<float4*>(a.raw)[m0] = make_float4(c0[0], c0[1], c0[2], sigma[0]);
+                if (valid1) reinterpret_cast<float4*>(a.raw)[m0 + 16] = make_float4(c1[0], c1[1], c1[2], sigma[1]);
             }
         });
     }
