@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--render-chunk", type=int, nargs="+", default=[65536, 4096],
                     help="rays per launch group of the frame render; the first value is the headline one, "
                          "4096 is the reference's eval_batch_size (render_nerf.py:55)")
+    ap.add_argument("--no-one-eighth", action="store_true",
+                    help="skip the 32-of-256-CU run (the metric's '1/8 GPU' reading), a child process under HSA_CU_MASK")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying HIP graphs")
     ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
     return ap.parse_args()
@@ -129,6 +131,32 @@ def render_section(mc, mf, pe, pv, device, args):
                 e["frac_of_hbm_peak"] = round(e["GB/s"] / HBM_PEAK_GBS, 4)
             sec["kernels"][name] = e
         out.append(sec)
+    return out
+
+
+def one_eighth_gpu(args):
+    """The same bench restricted to 32 of the 256 CUs (HSA_CU_MASK=0:0-31 in a child process, which must
+    be set before the runtime starts): BASELINE.json's metric reads "at 1/8 GPU".  Returns a summary, or a
+    note when the run failed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-one-eighth", "--steps", "20",
+           "--warmup", "5", "--rays-per-gpu", str(args.rays_per_gpu), "--precision", args.precision,
+           "--render-chunk", str(args.render_chunk[0])]
+    env = dict(os.environ, HSA_CU_MASK="0:0-31")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001  (a failed side measurement must not fail the bench)
+        return {"error": f"{type(e).__name__}: {e}"}
+    out = {"cu_mask": "HSA_CU_MASK=0:0-31 (32 of 256 CUs)", "rays_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+           "peak_TFLOP/s": MFMA_PEAK_TFLOPS / 8}
+    if d.get("render"):
+        k = d["render"][0]["kernels"].get("mlp_fwd", {})
+        out["render_s_per_frame"] = d["render"][0]["s_per_frame"]
+        out["render_rays_per_s"] = d["render"][0]["rays_per_s"]
+        if "TFLOP/s" in k:
+            out["mlp_fwd_TFLOP/s"] = k["TFLOP/s"]
+            out["mlp_fwd_frac_of_peak"] = round(k["TFLOP/s"] / (MFMA_PEAK_TFLOPS / 8), 4)
     return out
 
 
@@ -280,6 +308,8 @@ def main():
         }
         if world == 1 and not args.no_render:
             out["render"] = render_section(mc, mf, pe, pv, device, args)
+        if world == 1 and not args.no_one_eighth:
+            out["one_eighth_gpu"] = one_eighth_gpu(args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_steps)
         print(json.dumps(out), flush=True)
