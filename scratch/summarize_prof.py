@@ -16,7 +16,7 @@ cmd = open(os.path.join(src, "command.txt")).read().strip()
 
 # bench.py's kernel names -> device kernel names
 BENCH_NAMES = {"mlp_bwd_weights": "mlp_wgrad_kernel", "mlp_bwd_data": "mlp_dgrad_kernel",
-               "mlp_fwd_train": "mlp_fwd_kernel<0, true, false>", "mlp_fwd": "mlp_fwd_kernel<0, false, false>"}
+               "mlp_fwd_train": "mlp_fwd_kernel<0, true, false>", "mlp_fwd": "mlp_fwd16_kernel<0>"}
 
 
 def short(n):
