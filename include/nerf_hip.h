@@ -175,10 +175,13 @@ int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples);
 int nerf_mlp_fwd(int64_t n_rays, int S, const float *rays_o, const float *rays_d, const float *z,
                  const void *packed, int precision, float *raw, void *saved, void *stream);
 
-/* Forward on pre-encoded inputs (the literal NeRF.forward signature):
- * x_pts [M,63], x_views [M,27] fp32. */
+/* Forward on pre-encoded inputs (the literal NeRF.forward signature, models/nerf.py:155):
+ * x_pts [M,63], x_views [M,27] fp32.  The rows are first rewritten as 16-bit fragment units: into
+ * `saved` when it is given (they are two of its tensors), otherwise into `workspace`
+ * (nerf_mlp_encoded_workspace_bytes(M) bytes, 256-byte aligned); one of the two must be non-NULL. */
+int64_t nerf_mlp_encoded_workspace_bytes(int64_t n_samples);
 int nerf_mlp_fwd_encoded(int64_t M, const float *x_pts, const float *x_views, const void *packed,
-                         int precision, float *raw, void *saved, void *stream);
+                         int precision, float *raw, void *saved, void *workspace, void *stream);
 
 /* Backward: d_raw [M,4] -> d_params flat fp32 [NERF_MLP_NPARAMS] (overwritten,
  * not accumulated).  saved is what nerf_mlp_fwd wrote for the same samples.

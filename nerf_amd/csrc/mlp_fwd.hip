@@ -17,8 +17,8 @@ struct FwdArgs {
     const float* rays_o;  // [n_rays,3]
     const float* rays_d;  // [n_rays,3]
     const float* z;       // [M]
-    const float* x_pts;   // [M,63]  (encoded input mode)
-    const float* x_views; // [M,27]
+    const char* pe_units; // encoded input mode: the point / view encodings as 16-bit fragment units
+    const char* vpe_units;//   (written by encode_units_kernel), PE_KS resp. VPE_KS KiB per wave tile
     const char* packed;
     float* raw;           // [M,4]
     char* saved;          // nullable
@@ -66,20 +66,38 @@ __device__ __forceinline__ void encode(float px, float py, float pz, int h, type
     }
 }
 
-// fragments from pre-encoded rows x[m, 0..NF)
-template <int PREC, int L, int NKS, int NF>
-__device__ __forceinline__ void gather_encoded(const float* __restrict__ x, int64_t m, bool valid, int h,
-                                               typename Prec<PREC>::frag* out) {
+// Encoded input mode (the literal NeRF.forward(x_pts_encoded, x_views_encoded), nerf.py:155): the fp32
+// rows [M,63] and [M,27] are first rewritten as fragment units -- the layout of the saved PE / VPE
+// tensors -- by this bandwidth-bound kernel; the chain kernel then starts a pass with six 16-byte loads
+// per lane instead of gathering 90 strided floats per sample into registers.  One thread = one lane's
+// fragment of one unit.
+template <int PREC>
+__global__ __launch_bounds__(256) void encode_units_kernel(int64_t M, int64_t n_wt, const float* __restrict__ x_pts,
+                                                          const float* __restrict__ x_views, char* __restrict__ pe_units,
+                                                          char* __restrict__ vpe_units) {
     typedef typename Prec<PREC>::elem T;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    typedef typename Prec<PREC>::frag frag;
+    constexpr int UNITS = PE_KS + VPE_KS;
+    const int64_t total = n_wt * UNITS * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const int64_t u = i >> 6;
+        const int64_t wt = u / UNITS;
+        const int k = (int)(u - wt * UNITS);
+        const bool view = k >= PE_KS;
+        const int ks = view ? k - PE_KS : k;
+        const int c = lane & 31, h = lane >> 5;
+        const int64_t m = wt * WAVE_SAMPLES + c;
+        frag f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int f0 = pe_combo_feature(8 * ks + j, 0, L), f1 = pe_combo_feature(8 * ks + j, 1, L);
-            const int f = h ? f1 : f0;
-            const float v = (valid && f >= 0) ? x[m * NF + f] : 0.0f;
-            out[ks][j] = (T)v;
+            const int feat = pe_combo_feature(8 * ks + j, h, view ? 4 : 10);
+            float v = 0.0f;
+            if (m < M && feat >= 0) v = view ? x_views[m * VPE_FEATS + feat] : x_pts[m * PE_FEATS + feat];
+            f[j] = (T)v;
         }
+        char* dst = view ? vpe_units + (wt * VPE_KS + ks) * 1024 : pe_units + (wt * PE_KS + ks) * 1024;
+        *reinterpret_cast<frag*>(dst + c * 32 + h * 16) = f;
     }
 }
 
@@ -134,7 +152,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
         frag pe[PE_KS];
         float vx = 0.f, vy = 0.f, vz = 0.f;   // unit view direction (fused mode)
         if (ENCODED) {
-            gather_encoded<PREC, 10, PE_KS, PE_FEATS>(a.x_pts, m, valid, h, pe);
+#pragma unroll
+            for (int ks = 0; ks < PE_KS; ++ks)
+                pe[ks] = *reinterpret_cast<const frag*>(a.pe_units + (wt * PE_KS + ks) * 1024 + lane_off);
         } else {
             float px = 0.f, py = 0.f, pz = 0.f;
             if (valid) {
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
             }
             encode<PREC, 10, PE_KS>(px, py, pz, h, pe);
         }
-        if (SAVE) {
+        if (SAVE && !ENCODED) {          // in encoded mode the units already are the saved tensors
 #pragma unroll
             for (int ks = 0; ks < PE_KS; ++ks)
                 save_frag<PREC>(a.saved, saved_ks0(SV_PE), PE_KS, n_wt, wt, ks, lane_off, pe[ks]);
@@ -205,9 +225,14 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
 
         // L9: rgb_layers.0 on [feature, view encoding] -> relu -> G (first 8 k-steps of hb)
         frag vpe[VPE_KS];
-        if (ENCODED) gather_encoded<PREC, 4, VPE_KS, VPE_FEATS>(a.x_views, m, valid, h, vpe);
-        else encode<PREC, 4, VPE_KS>(vx, vy, vz, h, vpe);
-        if (SAVE) {
+        if (ENCODED) {
+#pragma unroll
+            for (int ks = 0; ks < VPE_KS; ++ks)
+                vpe[ks] = *reinterpret_cast<const frag*>(a.vpe_units + (wt * VPE_KS + ks) * 1024 + lane_off);
+        } else {
+            encode<PREC, 4, VPE_KS>(vx, vy, vz, h, vpe);
+        }
+        if (SAVE && !ENCODED) {
 #pragma unroll
             for (int ks = 0; ks < VPE_KS; ++ks)
                 save_frag<PREC>(a.saved, saved_ks0(SV_VPE), VPE_KS, n_wt, wt, ks, lane_off, vpe[ks]);
@@ -245,6 +270,7 @@ extern "C" int64_t nerf_mlp_saved_bytes(int64_t n_samples) {
 
 static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* stream) {
     NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    NERF_REQUIRE(encoded || a.saved != nullptr, NERF_E_NULL);
     if (a.M == 0) return NERF_OK;
     int64_t grid = a.n_tiles < 256 ? a.n_tiles : 256;   // one persistent workgroup per CU
     const dim3 g((unsigned)grid), b(CHAIN_THREADS);
@@ -253,7 +279,7 @@ static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* strea
 #define NERF_LAUNCH(P, SV, EN) hipLaunchKernelGGL((mlp_fwd_kernel<P, SV, EN>), g, b, 0, st, a)
 #define NERF_PICK(P)                                            \
     if (save) { if (encoded) NERF_LAUNCH(P, true, true); else NERF_LAUNCH(P, true, false); } \
-    else { if (encoded) NERF_LAUNCH(P, false, true); else NERF_LAUNCH(P, false, false); }
+    else { NERF_LAUNCH(P, false, true); }      /* fused inference is mlp_fwd16.hip's */
     if (precision == NERF_PREC_BF16) { NERF_PICK(NERF_PREC_BF16) } else { NERF_PICK(NERF_PREC_FP16) }
 #undef NERF_PICK
 #undef NERF_LAUNCH
@@ -278,13 +304,39 @@ extern "C" int nerf_mlp_fwd(int64_t n_rays, int S, const float* rays_o, const fl
     return launch_fwd(a, precision, false, stream);
 }
 
+extern "C" int64_t nerf_mlp_encoded_workspace_bytes(int64_t M) {
+    const int64_t n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
+    return n_tiles * 8 * (int64_t)(PE_KS + VPE_KS) * 1024;
+}
+
 extern "C" int nerf_mlp_fwd_encoded(int64_t M, const float* x_pts, const float* x_views, const void* packed,
-                                    int precision, float* raw, void* saved, void* stream) {
+                                    int precision, float* raw, void* saved, void* workspace, void* stream) {
     NERF_REQUIRE(x_pts && x_views && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(saved || workspace, NERF_E_NULL);
     NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
-    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
+                 nerf_aligned(workspace, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    if (M == 0) return NERF_OK;
     FwdArgs a{};
     a.M = M; a.n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES; a.S = 1;
-    a.x_pts = x_pts; a.x_views = x_views; a.packed = (const char*)packed; a.raw = raw; a.saved = (char*)saved;
+    a.packed = (const char*)packed; a.raw = raw; a.saved = (char*)saved;
+    const int64_t n_wt = a.n_tiles * 8;
+    // the encodings' units: the PE / VPE tensors of `saved` when activations are kept, else the workspace
+    char* pe_units = saved ? (char*)saved + (int64_t)saved_ks0(SV_PE) * n_wt * 1024 : (char*)workspace;
+    char* vpe_units = saved ? (char*)saved + (int64_t)saved_ks0(SV_VPE) * n_wt * 1024
+                            : (char*)workspace + (int64_t)PE_KS * n_wt * 1024;
+    a.pe_units = pe_units; a.vpe_units = vpe_units;
+    const int64_t threads = n_wt * (PE_KS + VPE_KS) * 64;
+    int64_t blocks = (threads + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (precision == NERF_PREC_BF16)
+        hipLaunchKernelGGL(encode_units_kernel<NERF_PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0,
+                           (hipStream_t)stream, M, n_wt, x_pts, x_views, pe_units, vpe_units);
+    else
+        hipLaunchKernelGGL(encode_units_kernel<NERF_PREC_FP16>, dim3((unsigned)blocks), dim3(256), 0,
+                           (hipStream_t)stream, M, n_wt, x_pts, x_views, pe_units, vpe_units);
+    const int rc = nerf_launch_status();
+    if (rc) return rc;
     return launch_fwd(a, precision, true, stream);
 }

@@ -365,8 +365,10 @@ class _FusedMLP(torch.autograd.Function):
                     check(lib.nerf_mlp_fwd(N, S, _p(rays_o), _p(rays_d), _p(z), _p(packed), prec, _p(raw), _p(saved),
                                            _stream(dev)), "nerf_mlp_fwd")
             else:
+                work = None if need_grad else torch.empty((int(lib.nerf_mlp_encoded_workspace_bytes(M)),),
+                                                          dtype=torch.uint8, device=dev)
                 check(lib.nerf_mlp_fwd_encoded(M, _p(x_pts), _p(x_views), _p(packed), prec, _p(raw), _p(saved),
-                                               _stream(dev)), "nerf_mlp_fwd_encoded")
+                                               _p(work), _stream(dev)), "nerf_mlp_fwd_encoded")
         ctx.M = M
         ctx.prec = prec
         ctx.shapes = [p.shape for p in params]

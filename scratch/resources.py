@@ -1,9 +1,9 @@
 """Per-kernel register / LDS usage of the MLP kernels (hipcc -Rpass-analysis=kernel-resource-usage)."""
-import re, subprocess, sys
+import os, re, subprocess, sys
 files = sys.argv[1:] or ["mlp_fwd", "mlp_bwd"]
 for f in files:
     out = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-pass-failed",
-                          "-mllvm", "-pragma-unroll-threshold=1000000", "-I../../include", "-c", f + ".hip",
+                          "-mllvm", "-pragma-unroll-threshold=1000000", "-I../../include", *os.environ.get("NERF_EXTRA", "").split(), "-c", f + ".hip",
                           "-o", "/tmp/" + f + ".o", "-Rpass-analysis=kernel-resource-usage"],
                          cwd="/root/repo/nerf_amd/csrc", capture_output=True, text=True).stderr
     cur = {}

@@ -389,3 +389,37 @@ def test_mse_pair_matches_torch(amd):
         assert not total.requires_grad
     with pytest.raises(ValueError):
         ops.mse_pair(a0, b0[:-1], t)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_mlp_inference_kernel_matches_training_forward(amd, precision):
+    """The no_grad forward (16x16x32 kernel) and the forward that keeps activations (32x32x16 kernel) are
+    two implementations of nerf.py:173-209 with the same rounding points; ragged sample counts exercise
+    partial column tiles, partial wave tiles and partial workgroup tiles."""
+    tol = 2e-3 if precision == "bf16" else 2.5e-4
+    m = amd_model(O.init_params(0), precision)
+    gen = torch.Generator().manual_seed(5)
+    for n_rays, S in ((1, 1), (1, 15), (3, 17), (5, 51), (2, 129), (7, 192), (1000, 3)):
+        ro = (torch.rand(n_rays, 3, generator=gen) * 4 - 2).to(DEV)
+        rd = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1).to(DEV) * 1.3
+        z = (torch.rand(n_rays, S, generator=gen) * 4 + 2).to(DEV)
+        with torch.no_grad():
+            inf = m.forward_rays(ro, rd, z)
+        trn = m.forward_rays(ro, rd, z)
+        assert trn.requires_grad and not inf.requires_grad and inf.shape == (n_rays, S, 4)
+        assert maxabs(inf, trn) < tol, (n_rays, S, maxabs(inf, trn))
+        # and both against the oracle's fp32 network on the same points
+        pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3).cpu()
+        vd = (rd / rd.norm(dim=-1, keepdim=True))[:, None, :].expand(n_rays, S, 3).reshape(-1, 3).cpu()
+        ref = O.mlp_forward(O.init_params(0), O.positional_encode(pts, 10), O.positional_encode(vd, 4))
+        assert maxabs(inf.reshape(-1, 4), ref) < (3e-3 if precision == "bf16" else 4e-4)
+    # the literal forward on encoded inputs, with and without autograd
+    pts = torch.rand(777, 3, generator=gen) * 6 - 3
+    vd = torch.nn.functional.normalize(torch.randn(777, 3, generator=gen), dim=-1)
+    ep, ev = O.positional_encode(pts, 10).to(DEV), O.positional_encode(vd, 4).to(DEV)
+    with torch.no_grad():
+        a = m(ep, ev)
+    b = m(ep, ev)
+    fused = m.forward_rays(pts.to(DEV), vd.to(DEV), torch.zeros(777, 1, device=DEV))
+    assert maxabs(a, b) == 0.0 and b.requires_grad
+    assert maxabs(a, fused.reshape(-1, 4)) < tol
