@@ -4,7 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): one training step of scripts/train_nerf.py:288-336 with its
+Workload (the single-GPU training configuration of the benchmark set): one training step of scripts/train_nerf.py:288-336 with its
 intended flat ray batch -- 1024 rays per GPU, 64 coarse + 128 fine samples, stratified jitter,
 stochastic hierarchical sampling, both 8x256 networks, loss, backward, Adam.  With N > 1 every rank
 runs that step on its own rays (weak scaling) and the gradients are summed with one RCCL
@@ -87,7 +87,7 @@ def build(device, precision):
 
 
 def render_section(mc, mf, pe, pv, device, args):
-    """BASELINE.json configs[2]: one 800x800 frame (640 000 rays, 64 + 128 samples, deterministic, no_grad),
+    """The full-frame render configuration: one 800x800 frame (640 000 rays, 64 + 128 samples, deterministic, no_grad),
     rays generated on the GPU, rendered in chunks.  Reports rays/s and the achieved rates of the MLP
     forward (MFMA) and of the compositing / sampling / ray-generation kernels (HBM, algorithmic bytes)."""
     from nerf_amd import ops
@@ -136,7 +136,7 @@ def render_section(mc, mf, pe, pv, device, args):
 
 def one_eighth_gpu(args):
     """The same bench restricted to 32 of the 256 CUs (HSA_CU_MASK=0:0-31 in a child process, which must
-    be set before the runtime starts): BASELINE.json's metric reads "at 1/8 GPU".  Returns a summary, or a
+    be set before the runtime starts): the headline metric is also quoted "at 1/8 GPU".  Returns a summary, or a
     note when the run failed."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-one-eighth", "--steps", "20",
@@ -300,7 +300,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "training step, %d rays/GPU, 64 coarse + 128 fine samples, coarse+fine 8x256 "
-                                   "NeRF, fwd+bwd+Adam (BASELINE.json configs[1])" % n,
+                                   "NeRF, fwd+bwd+Adam (benchmark configuration: single training step, batch 1024 rays)" % n,
                        "rays_per_gpu": n, "global_rays": n * world, "samples_per_ray": "64+192 evaluations",
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "launch_mode": "eager" if args.no_graph else "hipgraph replay (2 graphs per step)",
