@@ -35,7 +35,7 @@ MLP_DGRAD_FLOP = 2 * 557696     # backward-data MACs per sample (view/point-enco
 MLP_WGRAD_FLOP = 2 * 593408
 MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 peak, MI355X
 HBM_PEAK_GBS = 8000.0
-WGRAD_BYTES_PER_SAMPLE = 312 * 1024 // 32   # saved activations (158 KiB) + dZ (154 KiB) per 32 samples
+WGRAD_BYTES_PER_SAMPLE = 280 * 1024 // 32   # saved activations (142 KiB) + dZ (138 KiB) per 32 samples, each read once
 # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as
 # gfx950 requires for wide streams, plus WRITE_SIZE), written by scratch/summarize_prof.py
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
@@ -258,7 +258,7 @@ def main():
         avg_ms, launches, units, tot_ms = ktime[dom]
         if dom == "mlp_bwd_weights":
             # the weight-gradient pass contracts over samples: every saved-activation unit and every dZ
-            # unit is read once, 312 KiB per 32 samples; it is HBM-bound in this design
+            # unit is read once, 280 KiB per 32 samples; it is HBM-bound in this design
             achieved = units * WGRAD_BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9
             rl = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_sample": WGRAD_BYTES_PER_SAMPLE}

@@ -201,8 +201,9 @@ int64_t nerf_mlp_dz_bytes(int64_t n_samples);
 int64_t nerf_mlp_partial_bytes(int64_t n_samples);
 int nerf_mlp_bwd_data(int64_t M, const float *d_raw, const void *packed, int precision, const void *saved,
                       const float *grad_scale, void *dz, void *stream);
-int nerf_mlp_bwd_weights(int64_t M, const void *saved, const void *dz, int precision, const float *grad_scale,
-                         void *partial, int64_t partial_bytes, float *d_params, void *stream);
+int nerf_mlp_bwd_weights(int64_t M, const void *packed, const void *saved, const void *dz, int precision,
+                         const float *grad_scale, void *partial, int64_t partial_bytes, float *d_params,
+                         void *stream);
 
 /* Adam on a flat fp32 buffer -- the optimizer.step() of scripts/train_nerf.py:336
  * (torch.optim.Adam, no weight decay, no amsgrad).  step is 1-based. */

@@ -45,7 +45,7 @@ _SIGS = {
     "nerf_mlp_dz_bytes": (c_int64, [c_int64]),
     "nerf_mlp_partial_bytes": (c_int64, [c_int64]),
     "nerf_mlp_bwd_data": (c_int, [c_int64, P, P, c_int, P, P, P, P]),
-    "nerf_mlp_bwd_weights": (c_int, [c_int64, P, P, c_int, P, P, c_int64, P, P]),
+    "nerf_mlp_bwd_weights": (c_int, [c_int64, P, P, P, c_int, P, P, c_int64, P, P]),
     "nerf_adam_step_dev": (c_int, [c_int64, P, P, P, P, P, P]),
     "nerf_mse_pair": (c_int, [c_int64, P, P, P, P, P, P, P]),
     "nerf_adam_step": (c_int, [c_int64, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_float, P]),

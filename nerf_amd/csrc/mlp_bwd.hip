@@ -27,7 +27,7 @@ struct GemmDesc {
     int b_tensor, b_nks;            // cols: saved tensor, all its k-steps
     int has_bias;                   // this GEMM also produces the bias gradient of its rows
 };
-constexpr int NGEMM = 14;
+constexpr int NGEMM = 13;
 constexpr GemmDesc GEMMS[NGEMM] = {
     {0, 0, 16, SV_PE, 4, 1},          //  0: pts_linears.0
     {1, 0, 16, SV_H0 + 0, 16, 1},     //  1: pts_linears.1
@@ -38,11 +38,10 @@ constexpr GemmDesc GEMMS[NGEMM] = {
     {5, 0, 16, SV_H0 + 4, 16, 1},     //  6: pts_linears.5[:, 63:]
     {6, 0, 16, SV_H0 + 5, 16, 1},     //  7: pts_linears.6
     {7, 0, 16, SV_H0 + 6, 16, 1},     //  8: pts_linears.7
-    {8, 0, 16, SV_H0 + 7, 16, 1},     //  9: feature_linear
-    {8, 16, 1, SV_H0 + 7, 16, 1},     // 10: sigma_linear (row 0 of the unit)
-    {9, 0, 8, SV_F, 16, 1},           // 11: rgb_layers.0[:, :256]
-    {9, 0, 8, SV_VPE, 2, 0},          // 12: rgb_layers.0[:, 256:]
-    {10, 0, 1, SV_G, 8, 1},           // 13: rgb_layers.2 (rows 0..2)
+    {9, 0, 8, SV_H0 + 7, 16, 1},      //  9: P = dZ9^T H7 and sum dZ9: feature_linear and rgb_layers.0[:, :256] (factored)
+    {8, 0, 1, SV_H0 + 7, 16, 1},      // 10: sigma_linear (row 0 of the unit)
+    {9, 0, 8, SV_VPE, 2, 0},          // 11: rgb_layers.0[:, 256:]
+    {10, 0, 1, SV_G, 8, 1},           // 12: rgb_layers.2 (rows 0..2)
 };
 // partial block of GEMM g: [a_nks*16][b_nks*16] floats, then a_nks*16 bias floats
 constexpr int gemm_out_floats(int g) { return GEMMS[g].a_nks * 16 * GEMMS[g].b_nks * 16 + GEMMS[g].a_nks * 16; }
@@ -208,19 +207,18 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
         ring_enter<0>(ring, lds);            // chunk 0 of the pass: d0 starts behind the stream's front pad
         run_layer<PREC, bwd_block0(0), 4, 1, 0, 2>(ring, lds, db, db, mask_pre(NERF_IC(MB_G)), mask_epi(NERF_IC(9), da));
         // d1: dF = W_r0[:, :256]^T dZ9 (feature_linear has no activation) -> dZ8[0..255] in db; sigma joins as k-step 16
-        run_layer<PREC, bwd_block0(1), 8, G_KS, 0, 2>(ring, lds, da, da, [&](int) { return zero; },
+        // (dF stays in registers: the weight gradients that would read it are factored, mlp_common.hpp)
+        run_layer<PREC, bwd_block0(1), 8, G_KS, 0, 0>(ring, lds, da, da, [&](int) { return zero; },
                                                   [&](int mt, const f32x16& acc) {
             frag f0 = {}, f1 = {};
             grad_to_frags<PREC, false, 0>(acc, 0u, f0, f1);
             db[2 * mt] = f0; db[2 * mt + 1] = f1;
-            store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, 2 * mt, lane_off, f0);
-            store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, 2 * mt + 1, lane_off, f1);
         });
         frag dsig;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dsig[j] = (T)0.0f;
         dsig[0] = (T)dr.w;                                   // slot 256 = sigma_raw (lane half 0, element 0)
-        store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, H_KS, lane_off, dsig);
+        store_unit_frag<PREC>(a.dz, dz_ks0(8), DZ_KS[8], n_wt, wt, 0, lane_off, dsig);
         // d2: dH7 = [W_f; w_sigma]^T dZ8, masked by H7 > 0 -> dZ7 in da.  Before each masked layer: its
         // masks have landed; the next layer's start their way into the other buffer.
 #define NERF_MASKED(D, NK1, IN, IN1, BUF, NEXT_TENSOR, NEXT_BUF, DZL, OUT)                                   \
@@ -497,10 +495,10 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     while (g + 1 < NGEMM && (int)blockIdx.x >= a.jobs.job0[g + 1]) ++g;
     // shape dispatch (workgroup-uniform): <A units, B units, wave grid, tiles per wave>
     if (g == 0 || g == 5) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, g, lds);
+    else if (g == 9) wgrad_body<PREC, 8, 16, 4, 2, 1, 4>(a, g, lds);
     else if (g == 10) wgrad_body<PREC, 1, 16, 1, 8, 1, 1>(a, g, lds);
-    else if (g == 11) wgrad_body<PREC, 8, 16, 4, 2, 1, 4>(a, g, lds);
-    else if (g == 12) wgrad_body<PREC, 8, 2, 4, 1, 1, 1>(a, g, lds);
-    else if (g == 13) wgrad_body<PREC, 1, 8, 1, 4, 1, 1>(a, g, lds);
+    else if (g == 11) wgrad_body<PREC, 8, 2, 4, 1, 1, 1>(a, g, lds);
+    else if (g == 12) wgrad_body<PREC, 1, 8, 1, 4, 1, 1>(a, g, lds);
     else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, g, lds);
 }
 
@@ -523,9 +521,11 @@ __device__ __forceinline__ int pe_pos(int f, int L) {
 struct ReduceArgs {
     const float* partial;
     float* d_params;
+    float* prod;            // [128][256]: P = dZ9^T H7 in feature order, for mlp_post_kernel
     const float* scale;     // nullable: divide by *scale
     JobTable jobs;
 };
+constexpr int PROD_FLOATS = 128 * 256;
 
 __device__ __forceinline__ float sum_partials(const ReduceArgs& a, int g, int idx) {
     const float* p = a.partial + a.jobs.part_off[g] + idx;
@@ -538,7 +538,14 @@ __device__ __forceinline__ float sum_partials(const ReduceArgs& a, int g, int id
 
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N_PARAMS) return;
+    if (e >= N_PARAMS + PROD_FLOATS) return;
+    if (e >= N_PARAMS) {                                // the product P, handed to mlp_post_kernel
+        const int k = (e - N_PARAMS) >> 8, i = (e - N_PARAMS) & 255;
+        float v = sum_partials(a, 9, hidden_pos(k) * 256 + hidden_pos(i));
+        if (a.scale) v = v / *a.scale;
+        a.prod[e - N_PARAMS] = v;
+        return;
+    }
     int g, row, col = -1;      // col < 0: bias element
     if (e < OFF_W1) {                                   // pts_linears.0
         g = 0;
@@ -560,18 +567,16 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
     } else if (e < OFF_WF) {                            // sigma_linear
         g = 10; row = 0;
         if (e < OFF_BS) col = hidden_pos(e - OFF_WS);
-    } else if (e < OFF_WR0) {                           // feature_linear
-        g = 9;
-        const int r = e - OFF_WF;
-        if (r < 65536) { row = hidden_pos(r >> 8); col = hidden_pos(r & 255); } else row = hidden_pos(r - 65536);
+    } else if (e < OFF_WR0) {                           // feature_linear: mlp_post_kernel
+        return;
     } else if (e < OFF_WR2) {                           // rgb_layers.0
         if (e < OFF_BR0) {
             const int o = (e - OFF_WR0) / 283, i = (e - OFF_WR0) % 283;
-            row = hidden_pos(o);
-            if (i < 256) { g = 11; col = hidden_pos(i); } else { g = 12; col = pe_pos(i - 256, 4); }
-        } else { g = 11; row = hidden_pos(e - OFF_BR0); }
+            if (i < 256) return;                        // mlp_post_kernel
+            g = 11; row = hidden_pos(o); col = pe_pos(i - 256, 4);
+        } else { g = 9; row = hidden_pos(e - OFF_BR0); }
     } else {                                            // rgb_layers.2
-        g = 13;
+        g = 12;
         if (e < OFF_BR2) { row = (e - OFF_WR2) / 128; col = hidden_pos((e - OFF_WR2) % 128); } else row = e - OFF_BR2;
     }
     const int R = GEMMS[g].a_nks * 16, C = GEMMS[g].b_nks * 16;
@@ -579,6 +584,37 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
     float v = sum_partials(a, g, idx);
     if (a.scale) v = v / *a.scale;
     a.d_params[e] = v;
+}
+
+// The factored gradients (mlp_common.hpp, saved-tensor layout): with P = dZ9^T H7 [128][256] and
+// s = sum over samples of dZ9 (= d rgb_layers.0.bias, already in d_params),
+//   d feature_linear.weight[o][i] = sum_k W_r0[k][o] P[k][i]          d feature_linear.bias[o] = sum_k W_r0[k][o] s[k]
+//   d rgb_layers.0.weight[k][o]   = sum_i P[k][i] W_f[o][i] + s[k] b_f[o]
+// `post` holds the forward's (rounded) W_f, b_f and W_r0[:, :256].  98 304 + 256 outputs, 25 MFLOP.
+__global__ __launch_bounds__(256) void mlp_post_kernel(const float* __restrict__ prod, const float* __restrict__ post,
+                                                       float* __restrict__ d_params) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* wf = post + POST_WF;
+    const float* bf = post + POST_BF;
+    const float* wr0 = post + POST_WR0;
+    const float* s = d_params + OFF_BR0;
+    if (e < 256 * 256) {                                 // feature_linear.weight
+        const int o = e >> 8, i = e & 255;
+        float acc = 0.f;
+        for (int k = 0; k < 128; ++k) acc = fmaf(wr0[k * 256 + o], prod[k * 256 + i], acc);
+        d_params[OFF_WF + e] = acc;
+    } else if (e < 256 * 256 + 256) {                    // feature_linear.bias
+        const int o = e - 256 * 256;
+        float acc = 0.f;
+        for (int k = 0; k < 128; ++k) acc = fmaf(wr0[k * 256 + o], s[k], acc);
+        d_params[OFF_BF + o] = acc;
+    } else if (e < 256 * 256 + 256 + 128 * 256) {        // rgb_layers.0.weight[:, :256]
+        const int r = e - (256 * 256 + 256);
+        const int k = r >> 8, o = r & 255;
+        float acc = s[k] * bf[o];
+        for (int i = 0; i < 256; ++i) acc = fmaf(prod[k * 256 + i], wf[o * 256 + i], acc);
+        d_params[OFF_WR0 + k * 283 + o] = acc;
+    }
 }
 
 }  // namespace mlp
@@ -591,7 +627,7 @@ static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 extern "C" int64_t nerf_mlp_partial_bytes(int64_t n_samples) {
     const int64_t n_wt = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
     const JobTable t = make_jobs(n_wt > 0 ? n_wt : 1);
-    return round_up(partial_floats(t) * 4, 256);
+    return round_up(partial_floats(t) * 4, 256) + (int64_t)PROD_FLOATS * 4;     // partial blocks, then the product P
 }
 
 extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) {
@@ -629,7 +665,7 @@ extern "C" int nerf_mlp_bwd_data(int64_t M, const float* d_raw, const void* pack
     return nerf_launch_status();
 }
 
-extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* saved, const void* dz, int precision,
+extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* packed, const void* saved, const void* dz, int precision,
                                     const float* grad_scale, void* partial, int64_t partial_bytes, float* d_params,
                                     void* stream) {
     int rc = check_bwd_common(M, precision);
@@ -640,11 +676,13 @@ extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* saved, const void* dz
         hipError_t e = hipMemsetAsync(d_params, 0, sizeof(float) * N_PARAMS, st);
         return e == hipSuccess ? NERF_OK : (int)e;
     }
-    NERF_REQUIRE(saved && dz && partial, NERF_E_NULL);
-    NERF_REQUIRE(nerf_aligned(saved, 256) && nerf_aligned(dz, 256) && nerf_aligned(partial, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(packed && saved && dz && partial, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(packed, 256) && nerf_aligned(saved, 256) && nerf_aligned(dz, 256) &&
+                     nerf_aligned(partial, 256), NERF_E_ALIGN);
     const int64_t n_wt = (M + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
     const JobTable jobs = make_jobs(n_wt);
-    NERF_REQUIRE(partial_bytes >= partial_floats(jobs) * 4, NERF_E_WORKSPACE);
+    const int64_t prod_off = round_up(partial_floats(jobs) * 4, 256);
+    NERF_REQUIRE(partial_bytes >= prod_off + (int64_t)PROD_FLOATS * 4, NERF_E_WORKSPACE);
 
     WgradArgs w{};
     w.n_wt = n_wt; w.saved = (const char*)saved; w.dz = (const char*)dz; w.partial = (float*)partial; w.jobs = jobs;
@@ -656,7 +694,12 @@ extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* saved, const void* dz
 
     ReduceArgs r{};
     r.partial = (const float*)partial; r.d_params = d_params; r.scale = grad_scale; r.jobs = jobs;
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, st, r);
+    r.prod = reinterpret_cast<float*>((char*)partial + prod_off);
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((N_PARAMS + PROD_FLOATS + 255) / 256), dim3(256), 0, st, r);
+    rc = nerf_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp_post_kernel, dim3((256 * 256 + 256 + 128 * 256 + 255) / 256), dim3(256), 0, st, r.prod,
+                       reinterpret_cast<const float*>((const char*)packed + PACK_POST_OFF), d_params);
     return nerf_launch_status();
 }
 
@@ -674,6 +717,6 @@ extern "C" int nerf_mlp_bwd(int64_t M, const float* d_raw, const void* packed, i
     const int64_t dzb = nerf_mlp_dz_bytes(M);
     rc = nerf_mlp_bwd_data(M, d_raw, packed, precision, saved, grad_scale, workspace, stream);
     if (rc) return rc;
-    return nerf_mlp_bwd_weights(M, saved, workspace, precision, grad_scale, (char*)workspace + dzb,
+    return nerf_mlp_bwd_weights(M, packed, saved, workspace, precision, grad_scale, (char*)workspace + dzb,
                                 workspace_bytes - dzb, d_params, stream);
 }

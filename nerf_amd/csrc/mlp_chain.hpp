@@ -66,8 +66,9 @@ __device__ __forceinline__ void ring_init(Ring& r, char* lds, const void* stream
 //    share of the chunk about to be read is in LDS;
 //  - the barrier extends that to every wave's share, and also says every wave has finished
 //    reading the previous chunk, whose slot is the one refilled next.
-//  - YOUNGER: a lower bound on the VMEM operations (stores of saved tensors) this wave issued after
-//    its newest chunk of DMA; they complete after it, so they may stay in flight as well.
+//  - YOUNGER: a lower bound on the other VMEM operations (stores of saved tensors) this wave issued
+//    after it requested the chunk it now waits for; they complete after it (the counter is in order),
+//    so they may stay in flight as well.
 //  - SIDE: a kernel that issues a batch of SIDE further LDS-DMA copies right after a chunk entry (inputs
 //    of its next pass) sets r.extra_enters = 2: at the next two entries the batch is younger than the
 //    chunk waited for and may stay in flight; from the third entry on it is older and has landed.
@@ -158,10 +159,13 @@ constexpr int pf_lo(int B0, int NB, int i) {
     return pf_hi(B0, NB, i - 1) + 1;
 }
 
-// tile epilogues of this layer that ran during the CHUNK_BLOCKS blocks before block i
+// Tile epilogues of this layer that ran during the two chunks before block i.  The chunk entered at
+// block i was requested two entries earlier, so everything issued during those two chunks -- one chunk of
+// ring DMA and the stores of these epilogues -- is younger than it and may stay in flight; a store then
+// has two chunk times, not one, to be acknowledged before it would hold up a chunk entry.
 constexpr int tiles_ended_before(int NT, int NK, int i) {
     int n = 0;
-    for (int j = (i > CHUNK_BLOCKS ? i - CHUNK_BLOCKS : 0); j < i; ++j) n += (stream_ks(NT, NK, j) == NK - 1);
+    for (int j = (i > 2 * CHUNK_BLOCKS ? i - 2 * CHUNK_BLOCKS : 0); j < i; ++j) n += (stream_ks(NT, NK, j) == NK - 1);
     return n;
 }
 
@@ -222,7 +226,9 @@ __device__ __forceinline__ void run_layer(Ring& ring, char* lds, const typename 
         if (b % CHUNK_BLOCKS == 0) {
             // folds to one call once the loop is unrolled
             const int younger = VM_PER_TILE * tiles_ended_before(NT, NK, i);
-            if (younger >= 8) ring_enter<8>(ring, lds);
+            if (younger >= 16) ring_enter<16>(ring, lds);
+            else if (younger >= 12) ring_enter<12>(ring, lds);
+            else if (younger >= 8) ring_enter<8>(ring, lds);
             else if (younger >= 4) ring_enter<4>(ring, lds);
             else if (younger >= 2) ring_enter<2>(ring, lds);
             else ring_enter<0>(ring, lds);

@@ -162,7 +162,11 @@ constexpr int64_t PACK_FWD_OFF = 0;
 constexpr int64_t PACK_BWD_OFF = PACK_FWD_OFF + (int64_t)FWD_BLOCKS * BLOCK_BYTES;
 constexpr int64_t PACK_BIAS_OFF = PACK_BWD_OFF + (int64_t)BWD_BLOCKS * BLOCK_BYTES;
 constexpr int64_t PACK_F16_OFF = (PACK_BIAS_OFF + (int64_t)BIAS_FLOATS * 4 + 1023) / 1024 * 1024;
-constexpr int64_t PACK_BYTES = PACK_F16_OFF + (int64_t)F16_BLOCKS * BLOCK_BYTES;
+// fp32 copies, rounded to the operand type, of the two matrices the factored gradients above multiply
+// with: W_f [256][256], b_f [256] (exact), W_r0[:, :256] [128][256]
+constexpr int64_t PACK_POST_OFF = PACK_F16_OFF + (int64_t)F16_BLOCKS * BLOCK_BYTES;
+constexpr int POST_WF = 0, POST_BF = 256 * 256, POST_WR0 = POST_BF + 256, POST_FLOATS = POST_WR0 + 128 * 256;
+constexpr int64_t PACK_BYTES = PACK_POST_OFF + (int64_t)POST_FLOATS * 4;
 
 // ---- slot maps --------------------------------------------------------------------------------
 __host__ __device__ constexpr int slot_of(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
@@ -194,15 +198,21 @@ __host__ __device__ constexpr int pe_slot_feature(int slot, int L) {
 // [32 samples][16 positions] of 16-bit values, position p = 8*h + j <-> slot(ks, h, j), i.e. lane
 // l = sample + 32*h stores its 16-byte fragment at byte 32*sample + 16*h.
 // Tensors are stored tensor-major: tensor t starts at unit  SAVED_KS0[t] * n_wave_tiles.
-//   saved: PE(4) H0..H7(16 each) F(16) VPE(2) G(8)
-enum { SV_PE = 0, SV_H0 = 1, SV_F = 9, SV_VPE = 10, SV_G = 11, SV_NT = 12 };
-constexpr int SAVED_KS[SV_NT] = {4, 16, 16, 16, 16, 16, 16, 16, 16, 16, 2, 8};
+//   saved: PE(4) H0..H7(16 each) VPE(2) G(8)
+// The feature vector F = W_f H7 + b_f (no activation) and its gradient dF are NOT kept: the two weight
+// gradients that would need them factor through one product over samples, P = dZ9^T H7 [128 x 256]:
+//   d rgb_layers.0.weight[:, :256] = sum_s dZ9 F^T = P W_f^T + (sum_s dZ9) b_f^T
+//   d feature_linear.weight        = sum_s dF H7^T = W_r0[:, :256]^T P,     d feature_linear.bias = W_r0[:, :256]^T sum_s dZ9
+// (weights-only products, done after the reduction), which saves 32 KiB per 32 samples of stores and
+// as much of loads.
+enum { SV_PE = 0, SV_H0 = 1, SV_VPE = 9, SV_G = 10, SV_NT = 11 };
+constexpr int SAVED_KS[SV_NT] = {4, 16, 16, 16, 16, 16, 16, 16, 16, 2, 8};
 constexpr int saved_ks0(int t) { int k = 0; for (int i = 0; i < t; ++i) k += SAVED_KS[i]; return k; }
-constexpr int SAVED_UNITS = saved_ks0(SV_NT);   // 158 KiB per 32 samples
-//   gradients dZ of each layer's pre-activation: L0..L7 (16 each), L8 (17: 256 feature + sigma), L9 (8), L10 (1)
-constexpr int DZ_KS[NLAYERS] = {16, 16, 16, 16, 16, 16, 16, 16, 17, 8, 1};
+constexpr int SAVED_UNITS = saved_ks0(SV_NT);   // 142 KiB per 32 samples
+//   gradients dZ of each layer's pre-activation: L0..L7 (16 each), L8 (1: sigma only, see above), L9 (8), L10 (1)
+constexpr int DZ_KS[NLAYERS] = {16, 16, 16, 16, 16, 16, 16, 16, 1, 8, 1};
 constexpr int dz_ks0(int l) { int k = 0; for (int i = 0; i < l; ++i) k += DZ_KS[i]; return k; }
-constexpr int DZ_UNITS = dz_ks0(NLAYERS);       // 154 KiB per 32 samples
+constexpr int DZ_UNITS = dz_ks0(NLAYERS);       // 138 KiB per 32 samples
 
 // ---- ReLU sign masks -----------------------------------------------------------------------------
 // The backward-data chain needs only the sign of each post-ReLU activation.  Behind the saved units

@@ -211,13 +211,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
 
         // L8: feature_linear (no activation) -> ha, sigma_linear -> row 0 of tile 8
         float sigma = 0.f;
-        run_layer<PREC, fwd_block0(8), 9, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(8), [&](int mt, const f32x16& acc) {
+        run_layer<PREC, fwd_block0(8), 9, H_KS, 0, 0>(ring, lds, hb, hb, NERF_BIAS(8), [&](int mt, const f32x16& acc) {
             if (mt < 8) {
-                tile_to_frags<PREC, false>(acc, ha[2 * mt], ha[2 * mt + 1]);
-                if (SAVE) {
-                    save_frag<PREC>(a.saved, saved_ks0(SV_F), H_KS, n_wt, wt, 2 * mt, lane_off, ha[2 * mt]);
-                    save_frag<PREC>(a.saved, saved_ks0(SV_F), H_KS, n_wt, wt, 2 * mt + 1, lane_off, ha[2 * mt + 1]);
-                }
+                tile_to_frags<PREC, false>(acc, ha[2 * mt], ha[2 * mt + 1]);     // F is not kept (mlp_common.hpp)
             } else {
                 sigma = acc[0];
             }

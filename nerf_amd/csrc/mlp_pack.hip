@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
     T* f16 = reinterpret_cast<T*>(out + PACK_F16_OFF);
     float* bias = reinterpret_cast<float*>(out + PACK_BIAS_OFF);
     constexpr int64_t NF = (int64_t)FWD_BLOCKS * 512, NB = (int64_t)BWD_BLOCKS * 512, N16 = (int64_t)F16_BLOCKS * 512;
-    const int64_t total = NF + NB + BIAS_FLOATS + N16;
+    const int64_t total = NF + NB + BIAS_FLOATS + N16 + POST_FLOATS;
+    float* post = reinterpret_cast<float*>(out + PACK_POST_OFF);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         if (e < NF) {
@@ -139,6 +140,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
         } else if (e < NF + NB + BIAS_FLOATS) {
             const int i = (int)(e - NF - NB);
             bias[i] = bias_value(P, i / BIAS_STRIDE, i % BIAS_STRIDE);
+        } else if (e >= NF + NB + BIAS_FLOATS + N16) {
+            const int i = (int)(e - NF - NB - BIAS_FLOATS - N16);
+            float v;
+            if (i < POST_BF) v = (float)(T)P[OFF_WF + i];
+            else if (i < POST_WR0) v = P[OFF_BF + (i - POST_BF)];
+            else { const int k = (i - POST_WR0) >> 8, o = (i - POST_WR0) & 255; v = (float)(T)P[OFF_WR0 + k * 283 + o]; }
+            post[i] = v;
         } else {
             const int64_t ef = e - NF - NB - BIAS_FLOATS;
             int b = (int)(ef >> 9);

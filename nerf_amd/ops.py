@@ -398,7 +398,7 @@ class _FusedMLP(torch.autograd.Function):
                 check(lib.nerf_mlp_bwd_data(M, _p(d_raw), _p(ctx.packed), ctx.prec, _p(ctx.saved_acts), _p(scale),
                                             _p(dz), st), "nerf_mlp_bwd_data")
             with _timed("mlp_bwd_weights", dev, M):
-                check(lib.nerf_mlp_bwd_weights(M, _p(ctx.saved_acts), _p(dz), ctx.prec, _p(scale), _p(part),
+                check(lib.nerf_mlp_bwd_weights(M, _p(ctx.packed), _p(ctx.saved_acts), _p(dz), ctx.prec, _p(scale), _p(part),
                                                part_bytes, _p(d_flat), st), "nerf_mlp_bwd_weights")
         ctx.saved_acts = None
         grads = []

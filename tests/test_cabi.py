@@ -52,10 +52,10 @@ def test_argument_errors_without_gpu():
     lib.nerf_sort_rows.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     assert lib.nerf_sort_rows(1, 2000, ctypes.c_void_p(16), 0, None, ctypes.c_void_p(16), None) == -2
     lib.nerf_mlp_packed_bytes.restype = ctypes.c_int64
-    assert lib.nerf_mlp_packed_bytes() == (1216 + 1120) * 1024 + 13312 + 1184 * 1024
+    assert lib.nerf_mlp_packed_bytes() == (1216 + 1120) * 1024 + 13312 + 1184 * 1024 + (256 * 256 + 256 + 128 * 256) * 4
     lib.nerf_mlp_saved_bytes.restype = ctypes.c_int64
     lib.nerf_mlp_saved_bytes.argtypes = [ctypes.c_int64]
-    assert lib.nerf_mlp_saved_bytes(1) == 8 * (158 + 9) * 1024 and lib.nerf_mlp_saved_bytes(257) == 16 * (158 + 9) * 1024
+    assert lib.nerf_mlp_saved_bytes(1) == 8 * (142 + 9) * 1024 and lib.nerf_mlp_saved_bytes(257) == 16 * (142 + 9) * 1024
 
 
 def test_cpu_tensors_are_rejected():
