@@ -273,7 +273,8 @@ def main():
                     "algorithmic_bytes_per_launch": round(units * WGRAD_BYTES_PER_SAMPLE) if rl["bound"] == "hbm" else None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
                     "samples_per_launch": units,
-                    "timing": "HIP events on the launch stream around each launch, %d eager steps of the same "
+                    "timing": "HIP events on the launch stream around each C-ABI call (for mlp_bwd_weights: the "
+                              "contraction kernel plus its two small reduction kernels), %d eager steps of the same "
                               "training step run right after the timed region" % args.kernel_steps}
         kernels = {}
         for k, (a_ms, cnt, u, tot) in sorted(ktime.items()):
