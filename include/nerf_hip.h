@@ -158,8 +158,11 @@ int nerf_mse_pair(int64_t n_elements, const float *a, const float *b, const floa
 /* bytes of the packed-weight buffer (forward + transposed streams + biases) */
 int64_t nerf_mlp_packed_bytes(void);
 
-/* params: flat fp32 [NERF_MLP_NPARAMS]; packed: nerf_mlp_packed_bytes() bytes, 256-byte aligned. */
-int nerf_mlp_pack(const float *params, int precision, void *packed, void *stream);
+/* params: flat fp32 [NERF_MLP_NPARAMS]; packed: nerf_mlp_packed_bytes() bytes, 256-byte aligned.
+ * streams: which weight streams to (re)write -- NERF_PACK_TRAIN for nerf_mlp_fwd with `saved`,
+ * nerf_mlp_fwd_encoded and the backward, NERF_PACK_INFER for nerf_mlp_fwd without `saved`, or both. */
+enum { NERF_PACK_TRAIN = 1, NERF_PACK_INFER = 2 };
+int nerf_mlp_pack(const float *params, int precision, int streams, void *packed, void *stream);
 
 /* bytes of activations the training forward saves per sample (for nerf_mlp_bwd) */
 int64_t nerf_mlp_saved_bytes(int64_t n_samples);

@@ -35,7 +35,7 @@ _SIGS = {
     "nerf_sample_merge": (c_int, [c_int64, c_int, P, P, c_int, P, P, P, P]),
     "nerf_sort_rows": (c_int, [c_int64, c_int, P, c_int, P, P, P]),
     "nerf_mlp_packed_bytes": (c_int64, []),
-    "nerf_mlp_pack": (c_int, [P, c_int, P, P]),
+    "nerf_mlp_pack": (c_int, [P, c_int, c_int, P, P]),
     "nerf_mlp_saved_bytes": (c_int64, [c_int64]),
     "nerf_mlp_bwd_workspace_bytes": (c_int64, [c_int64]),
     "nerf_mlp_fwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P, P]),

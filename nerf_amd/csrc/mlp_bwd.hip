@@ -532,7 +532,8 @@ __device__ __forceinline__ float sum_partials(const ReduceArgs& a, int g, int id
     const int n = a.jobs.splits[g];
     const int stride = gemm_out_floats(g);
     float s = 0.f;
-    for (int i = 0; i < n; ++i) s += p[(int64_t)i * stride];
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) s += p[(int64_t)i * stride];      // fixed order; loads of eight terms in flight
     return s;
 }
 
@@ -591,28 +592,35 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
 //   d feature_linear.weight[o][i] = sum_k W_r0[k][o] P[k][i]          d feature_linear.bias[o] = sum_k W_r0[k][o] s[k]
 //   d rgb_layers.0.weight[k][o]   = sum_i P[k][i] W_f[o][i] + s[k] b_f[o]
 // `post` holds the forward's (rounded) W_f, b_f and W_r0[:, :256].  98 304 + 256 outputs, 25 MFLOP.
+// One thread per output; consecutive threads read consecutive addresses of one operand and the same
+// address of the other.  The loops are unrolled so that sixteen terms' loads are in flight together
+// (a thread's chain of 128 or 256 dependent load-then-fma steps is otherwise latency-bound).
+constexpr int POST_OUTPUTS = 256 * 256 + 256 + 128 * 256;
 __global__ __launch_bounds__(256) void mlp_post_kernel(const float* __restrict__ prod, const float* __restrict__ post,
                                                        float* __restrict__ d_params) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const float* wf = post + POST_WF;
+    const float* wft = post + POST_WF;       // [in][out]
     const float* bf = post + POST_BF;
-    const float* wr0 = post + POST_WR0;
+    const float* wr0 = post + POST_WR0;      // [k][o]
     const float* s = d_params + OFF_BR0;
-    if (e < 256 * 256) {                                 // feature_linear.weight
+    if (e < 256 * 256) {                                 // feature_linear.weight[o][i]
         const int o = e >> 8, i = e & 255;
         float acc = 0.f;
+#pragma unroll 16
         for (int k = 0; k < 128; ++k) acc = fmaf(wr0[k * 256 + o], prod[k * 256 + i], acc);
         d_params[OFF_WF + e] = acc;
-    } else if (e < 256 * 256 + 256) {                    // feature_linear.bias
+    } else if (e < 256 * 256 + 256) {                    // feature_linear.bias[o]
         const int o = e - 256 * 256;
         float acc = 0.f;
+#pragma unroll 16
         for (int k = 0; k < 128; ++k) acc = fmaf(wr0[k * 256 + o], s[k], acc);
         d_params[OFF_BF + o] = acc;
-    } else if (e < 256 * 256 + 256 + 128 * 256) {        // rgb_layers.0.weight[:, :256]
+    } else if (e < POST_OUTPUTS) {                       // rgb_layers.0.weight[k][o], o < 256
         const int r = e - (256 * 256 + 256);
         const int k = r >> 8, o = r & 255;
         float acc = s[k] * bf[o];
-        for (int i = 0; i < 256; ++i) acc = fmaf(prod[k * 256 + i], wf[o * 256 + i], acc);
+#pragma unroll 16
+        for (int i = 0; i < 256; ++i) acc = fmaf(prod[k * 256 + i], wft[i * 256 + o], acc);
         d_params[OFF_WR0 + k * 283 + o] = acc;
     }
 }
@@ -698,7 +706,7 @@ extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* packed, const void* s
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((N_PARAMS + PROD_FLOATS + 255) / 256), dim3(256), 0, st, r);
     rc = nerf_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(mlp_post_kernel, dim3((256 * 256 + 256 + 128 * 256 + 255) / 256), dim3(256), 0, st, r.prod,
+    hipLaunchKernelGGL(mlp_post_kernel, dim3((POST_OUTPUTS + 255) / 256), dim3(256), 0, st, r.prod,
                        reinterpret_cast<const float*>((const char*)packed + PACK_POST_OFF), d_params);
     return nerf_launch_status();
 }

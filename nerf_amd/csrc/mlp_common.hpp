@@ -163,7 +163,7 @@ constexpr int64_t PACK_BWD_OFF = PACK_FWD_OFF + (int64_t)FWD_BLOCKS * BLOCK_BYTE
 constexpr int64_t PACK_BIAS_OFF = PACK_BWD_OFF + (int64_t)BWD_BLOCKS * BLOCK_BYTES;
 constexpr int64_t PACK_F16_OFF = (PACK_BIAS_OFF + (int64_t)BIAS_FLOATS * 4 + 1023) / 1024 * 1024;
 // fp32 copies, rounded to the operand type, of the two matrices the factored gradients above multiply
-// with: W_f [256][256], b_f [256] (exact), W_r0[:, :256] [128][256]
+// with: W_f transposed [in 256][out 256], b_f [256] (exact), W_r0[:, :256] [128][256]
 constexpr int64_t PACK_POST_OFF = PACK_F16_OFF + (int64_t)F16_BLOCKS * BLOCK_BYTES;
 constexpr int POST_WF = 0, POST_BF = 256 * 256, POST_WR0 = POST_BF + 256, POST_FLOATS = POST_WR0 + 128 * 256;
 constexpr int64_t PACK_BYTES = PACK_POST_OFF + (int64_t)POST_FLOATS * 4;

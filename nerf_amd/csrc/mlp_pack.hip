@@ -100,58 +100,69 @@ __device__ __forceinline__ float bias_value(const float* __restrict__ P, int L, 
     return row < 3 ? P[OFF_BR2 + row] : 0.0f;
 }
 
+// One thread produces one lane's 16-byte fragment of one block (or one fp32 of the bias / post tables).
+// `streams`: NERF_PACK_TRAIN = forward + backward streams and the post table, NERF_PACK_INFER = the
+// inference stream; the bias table is always written.
 template <int PREC>
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, char* __restrict__ out) {
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, char* __restrict__ out, int streams) {
     typedef typename Prec<PREC>::elem T;
-    T* fwd = reinterpret_cast<T*>(out + PACK_FWD_OFF);
-    T* bwd = reinterpret_cast<T*>(out + PACK_BWD_OFF);
-    T* f16 = reinterpret_cast<T*>(out + PACK_F16_OFF);
+    typedef typename Prec<PREC>::frag frag;
+    frag* fwd = reinterpret_cast<frag*>(out + PACK_FWD_OFF);
+    frag* bwd = reinterpret_cast<frag*>(out + PACK_BWD_OFF);
+    frag* f16 = reinterpret_cast<frag*>(out + PACK_F16_OFF);
     float* bias = reinterpret_cast<float*>(out + PACK_BIAS_OFF);
-    constexpr int64_t NF = (int64_t)FWD_BLOCKS * 512, NB = (int64_t)BWD_BLOCKS * 512, N16 = (int64_t)F16_BLOCKS * 512;
-    const int64_t total = NF + NB + BIAS_FLOATS + N16 + POST_FLOATS;
     float* post = reinterpret_cast<float*>(out + PACK_POST_OFF);
+    constexpr int64_t NF = (int64_t)FWD_BLOCKS * 64, NB = (int64_t)BWD_BLOCKS * 64, N16 = (int64_t)F16_BLOCKS * 64;
+    constexpr int64_t E_BWD = NF, E_BIAS = NF + NB, E_F16 = E_BIAS + BIAS_FLOATS, E_POST = E_F16 + N16;
+    constexpr int64_t total = E_POST + POST_FLOATS;
+    const bool train = streams & NERF_PACK_TRAIN, infer = streams & NERF_PACK_INFER;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
-        if (e < NF) {
-            int b = (int)(e >> 9);
-            const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
-            float v = 0.0f;
+        if (e < E_BWD) {
+            if (!train) continue;
+            int b = (int)(e >> 6);
+            const int lane = (int)e & 63;
+            frag f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (T)0.0f;
             if (b >= FWD_PAD && b < FWD_BLOCKS_REAL) {
                 b -= FWD_PAD;
                 int L = 0;
                 while (L + 1 < NLAYERS && b >= FWD_TILES[L] * FWD_KS[L]) { b -= FWD_TILES[L] * FWD_KS[L]; ++L; }
                 const int m = stream_tile(FWD_TILES[L], FWD_KS[L], b), ks = stream_ks(FWD_TILES[L], FWD_KS[L], b);
-                v = fwd_weight(P, L, 32 * m + (lane & 31), ks, slot_of(ks, lane >> 5, j));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    f[j] = (T)fwd_weight(P, L, 32 * m + (lane & 31), ks, slot_of(ks, lane >> 5, j));
             }
-            fwd[e] = (T)v;
-        } else if (e < NF + NB) {
-            const int64_t eb = e - NF;
-            int b = (int)(eb >> 9);
-            const int lane = (int)(eb >> 3) & 63, j = (int)eb & 7;
-            float v = 0.0f;
+            fwd[e] = f;
+        } else if (e < E_BIAS) {
+            if (!train) continue;
+            const int64_t eb = e - E_BWD;
+            int b = (int)(eb >> 6);
+            const int lane = (int)eb & 63;
+            frag f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (T)0.0f;
             if (b >= BWD_PAD && b < BWD_BLOCKS_REAL) {
                 b -= BWD_PAD;
                 int d = 0;
                 while (d + 1 < NBWD && b >= BWD_TILES[d] * BWD_KS[d]) { b -= BWD_TILES[d] * BWD_KS[d]; ++d; }
                 const int m = stream_tile(BWD_TILES[d], BWD_KS[d], b), ks = stream_ks(BWD_TILES[d], BWD_KS[d], b);
-                v = bwd_weight(P, d, 32 * m + (lane & 31), slot_of(ks, lane >> 5, j));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (T)bwd_weight(P, d, 32 * m + (lane & 31), slot_of(ks, lane >> 5, j));
             }
-            bwd[eb] = (T)v;
-        } else if (e < NF + NB + BIAS_FLOATS) {
-            const int i = (int)(e - NF - NB);
+            bwd[eb] = f;
+        } else if (e < E_F16) {
+            const int i = (int)(e - E_BIAS);
             bias[i] = bias_value(P, i / BIAS_STRIDE, i % BIAS_STRIDE);
-        } else if (e >= NF + NB + BIAS_FLOATS + N16) {
-            const int i = (int)(e - NF - NB - BIAS_FLOATS - N16);
-            float v;
-            if (i < POST_BF) v = (float)(T)P[OFF_WF + i];
-            else if (i < POST_WR0) v = P[OFF_BF + (i - POST_BF)];
-            else { const int k = (i - POST_WR0) >> 8, o = (i - POST_WR0) & 255; v = (float)(T)P[OFF_WR0 + k * 283 + o]; }
-            post[i] = v;
-        } else {
-            const int64_t ef = e - NF - NB - BIAS_FLOATS;
-            int b = (int)(ef >> 9);
-            const int lane = (int)(ef >> 3) & 63, j = (int)ef & 7;
-            float v = 0.0f;
+        } else if (e < E_POST) {
+            if (!infer) continue;
+            const int64_t ef = e - E_F16;
+            int b = (int)(ef >> 6);
+            const int lane = (int)ef & 63;
+            frag f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (T)0.0f;
             if (b >= F16_PAD && b < F16_BLOCKS_REAL) {
                 b -= F16_PAD;
                 int L = 0;
@@ -159,9 +170,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
                 const int rt = stream_tile(F16_TILES[L], F16_KS[L], b), ks = stream_ks(F16_TILES[L], F16_KS[L], b);
                 const int row = 16 * rt + (lane & 15);
                 const int rows = L < 8 ? 256 : (L == 8 ? 257 : (L == 9 ? 128 : 3));
-                if (row < rows) v = f16_weight(P, L, row, ks, lane >> 4, j);
+                if (row < rows) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = (T)f16_weight(P, L, row, ks, lane >> 4, j);
+                }
             }
-            f16[ef] = (T)v;
+            f16[ef] = f;
+        } else {
+            if (!train) continue;
+            const int i = (int)(e - E_POST);
+            float v;
+            if (i < POST_BF) { const int in = i >> 8, o = i & 255; v = (float)(T)P[OFF_WF + o * 256 + in]; }   // W_f transposed
+            else if (i < POST_WR0) v = P[OFF_BF + (i - POST_BF)];
+            else { const int k = (i - POST_WR0) >> 8, o = (i - POST_WR0) & 255; v = (float)(T)P[OFF_WR0 + k * 283 + o]; }
+            post[i] = v;
         }
     }
 }
@@ -171,16 +193,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
 
 extern "C" int64_t nerf_mlp_packed_bytes(void) { return nerf::mlp::PACK_BYTES; }
 
-extern "C" int nerf_mlp_pack(const float* params, int precision, void* packed, void* stream) {
+extern "C" int nerf_mlp_pack(const float* params, int precision, int streams, void* packed, void* stream) {
     NERF_REQUIRE(params && packed, NERF_E_NULL);
+    NERF_REQUIRE(streams >= 1 && streams <= (NERF_PACK_TRAIN | NERF_PACK_INFER), NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(packed, 256), NERF_E_ALIGN);
     NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
     const dim3 grid(1024), block(256);
     if (precision == NERF_PREC_BF16)
         hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_BF16>, grid, block, 0, (hipStream_t)stream, params,
-                           (char*)packed);
+                           (char*)packed, streams);
     else
         hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_FP16>, grid, block, 0, (hipStream_t)stream, params,
-                           (char*)packed);
+                           (char*)packed, streams);
     return nerf_launch_status();
 }

@@ -135,7 +135,9 @@ class NeRF(nn.Module):
                 flat = _consecutive_view(ps)
                 if flat is None:
                     flat = torch.cat([p.detach().reshape(-1) for p in ps])
-                self._packed = ops.mlp_pack(flat, self.precision)
+                # a training step only ever runs the training kernels on this snapshot of the weights
+                self._packed = ops.mlp_pack(flat, self.precision,
+                                            ops.PACK_TRAIN if training else ops.PACK_TRAIN | ops.PACK_INFER)
             self._pack_key = key
         return self._packed
 

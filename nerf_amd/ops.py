@@ -329,13 +329,20 @@ def sample_merge(z_coarse: torch.Tensor, weights_coarse: torch.Tensor, N_fine: i
 # fused MLP
 # ---------------------------------------------------------------------------
 
-def mlp_pack(flat_params: torch.Tensor, precision: str) -> torch.Tensor:
+PACK_TRAIN, PACK_INFER = 1, 2
+
+
+def mlp_pack(flat_params: torch.Tensor, precision: str, streams: int = PACK_TRAIN | PACK_INFER) -> torch.Tensor:
+    """Weight streams of one network.  ``streams`` limits the work to what the caller will run:
+    PACK_TRAIN (forward that keeps activations, encoded-input forward, backward) and / or PACK_INFER
+    (the no_grad ray forward); streams that are not written hold garbage."""
     flat = _gpu_f32(flat_params, "flat_params")
     if flat.numel() != _C.NERF_MLP_NPARAMS:
         raise ValueError(f"expected {_C.NERF_MLP_NPARAMS} parameters, got {flat.numel()}")
     packed = torch.empty((int(lib.nerf_mlp_packed_bytes()),), dtype=torch.uint8, device=flat.device)
     with torch.cuda.device(flat.device):
-        check(lib.nerf_mlp_pack(_p(flat), _C.PREC[precision], _p(packed), _stream(flat.device)), "nerf_mlp_pack")
+        check(lib.nerf_mlp_pack(_p(flat), _C.PREC[precision], int(streams), _p(packed), _stream(flat.device)),
+              "nerf_mlp_pack")
     return packed
 
 
