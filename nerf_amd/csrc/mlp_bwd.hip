@@ -4,15 +4,17 @@
 //  1. mlp_dgrad_kernel -- the backward-data chain.  Same structure as the forward: a wave owns 32
 //     samples, dZ of a layer (features in registers, samples on lanes) is the MFMA B operand of the
 //     next product dH_in = W^T dZ, weights stream through the LDS ring from the transposed block
-//     stream.  ReLU masks come from the saved activations.  Every layer's dZ is written out (16 bit)
-//     in [32 samples][16 positions] units for the weight-gradient pass.
-//  2. mlp_wgrad_kernel -- dW = sum over samples dZ x In^T: 14 GEMMs whose contraction index is the
+//     stream.  ReLU masks are the sign bits the forward kept, fetched by LDS-DMA.  Every layer's dZ
+//     (except dF, see "factored gradients" in mlp_common.hpp) is written out (16 bit) in
+//     [32 samples][16 positions] units for the weight-gradient pass.
+//  2. mlp_wgrad_kernel -- dW = sum over samples dZ x In^T: 13 GEMMs whose contraction index is the
 //     sample.  Units are DMA-copied into LDS as they are and read back with ds_read_b64_tr_b16,
 //     which delivers the [feature][8 samples] fragments the MFMA wants.  The sample axis is
 //     split across workgroups; each writes an fp32 partial block.  HBM-bound: every saved unit and
 //     every dZ unit is read once (a few are read twice), 128 flop per byte.
 //  3. mlp_reduce_kernel -- sums the partial blocks in fixed order (bitwise reproducible) and
-//     scatters them from slot order to the flat state_dict-order gradient buffer.
+//     scatters them from slot order to the flat state_dict-order gradient buffer; mlp_post_kernel then
+//     forms the two factored gradients from the reduced product P = dZ9^T H7.
 #include <type_traits>
 #include "mlp_chain.hpp"
 

@@ -25,9 +25,11 @@
 //
 // Weight stream.  For layer L, output tile m (32 rows), k-step ks: one 1 KiB block holding
 // lane l's A fragment at byte 16*l:  element j = W[32m + (l&31)][feature of slot(ks, l>>5, j)].
-// Blocks are stored in consumption order; 32 blocks form a 32 KiB chunk, the unit of the LDS
-// ring.  The forward stream has 1184 blocks (37 chunks); the backward (transposed) stream,
-// whose A operand is a 32-row tile of W^T, has 1100 blocks padded to 1120 (35 chunks).
+// Blocks are stored in consumption order (two output tiles at a time, k-steps interleaved, see
+// stream_tile); 32 blocks form a 32 KiB chunk, the unit of the LDS ring.  The training forward
+// stream has 1184 blocks behind a 16-block front pad (38 chunks); the backward (transposed) stream,
+// whose A operand is a 32-row tile of W^T, has 1100 blocks behind a 4-block pad (35 chunks).  The
+// inference forward uses a third stream tiled for v_mfma_f32_16x16x32 (see "inference stream").
 #pragma once
 #include "common.hpp"
 

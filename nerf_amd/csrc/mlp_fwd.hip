@@ -1,9 +1,12 @@
-// Fused positional encoding + 8x256 MLP forward (src/nerf_project/models/nerf.py:68-76, :173-209
-// and the point / view-direction set-up of render_rays, :409-421) on bf16/fp16 MFMA.
+// Training forward of the fused positional encoding + 8x256 MLP (src/nerf_project/models/nerf.py:68-76,
+// :173-209 and the point / view-direction set-up of render_rays, :409-421) on bf16/fp16
+// v_mfma_f32_32x32x16: the variant that keeps the activations for the backward pass, and the forward on
+// pre-encoded inputs (the literal NeRF.forward).  The no_grad ray forward is mlp_fwd16.hip.
 //
-// MFMA-bound: 1184 v_mfma_f32_32x32x16 per 32 samples (600 064 padded MAC/sample against
-// 593 408 algorithmic).  HBM traffic is 4 B (z) in and 16 B (raw) out per sample, plus the
-// optional saved activations for training.  Layout and schedule: mlp_common.hpp, mlp_chain.hpp.
+// 1184 MFMAs per 32 samples (600 064 padded MAC/sample against 593 408 algorithmic).  Every 16-bit
+// fragment the chain produces is also stored as a [32 samples][16 positions] unit -- the format the
+// weight-gradient pass reads -- together with one sign bit per activation for the backward-data chain:
+// 4.7 KiB per sample, which is what bounds this kernel.  Layout and schedule: mlp_common.hpp, mlp_chain.hpp.
 #include <type_traits>
 #include "mlp_chain.hpp"
 
