@@ -24,31 +24,36 @@ namespace mlp {
 // ------------------------------------------------------------------------------------------------
 // weight-gradient GEMM table
 // ------------------------------------------------------------------------------------------------
+// A GEMM's row operand is one or two runs of dZ units, its column operand one or two saved tensors:
+// operands that two products share are read once (dZ5 meets both halves of the skip layer's input, H7
+// meets dZ9 and d sigma, dZ9 meets H7 and the view encoding).
 struct GemmDesc {
-    int dz_layer, a_ks0, a_nks;     // rows: k-steps [a_ks0, a_ks0 + a_nks) of dZ[dz_layer]
-    int b_tensor, b_nks;            // cols: saved tensor, all its k-steps
-    int has_bias;                   // this GEMM also produces the bias gradient of its rows
+    int a_layer, a_nks;             // rows: all k-steps of dZ[a_layer] ...
+    int a2_layer, a2_nks;           // ... then those of dZ[a2_layer] (a2_nks = 0: none)
+    int b_tensor, b_nks;            // cols: saved tensor b_tensor ...
+    int b2_tensor, b2_nks;          // ... then b2_tensor (b2_nks = 0: none)
 };
-constexpr int NGEMM = 13;
+constexpr int NGEMM = 10;
 constexpr GemmDesc GEMMS[NGEMM] = {
-    {0, 0, 16, SV_PE, 4, 1},          //  0: pts_linears.0
-    {1, 0, 16, SV_H0 + 0, 16, 1},     //  1: pts_linears.1
-    {2, 0, 16, SV_H0 + 1, 16, 1},     //  2
-    {3, 0, 16, SV_H0 + 2, 16, 1},     //  3
-    {4, 0, 16, SV_H0 + 3, 16, 1},     //  4
-    {5, 0, 16, SV_PE, 4, 0},          //  5: pts_linears.5[:, :63]
-    {5, 0, 16, SV_H0 + 4, 16, 1},     //  6: pts_linears.5[:, 63:]
-    {6, 0, 16, SV_H0 + 5, 16, 1},     //  7: pts_linears.6
-    {7, 0, 16, SV_H0 + 6, 16, 1},     //  8: pts_linears.7
-    {9, 0, 8, SV_H0 + 7, 16, 1},      //  9: P = dZ9^T H7 and sum dZ9: feature_linear and rgb_layers.0[:, :256] (factored)
-    {8, 0, 1, SV_H0 + 7, 16, 1},      // 10: sigma_linear (row 0 of the unit)
-    {9, 0, 8, SV_VPE, 2, 0},          // 11: rgb_layers.0[:, 256:]
-    {10, 0, 1, SV_G, 8, 1},           // 12: rgb_layers.2 (rows 0..2)
+    {0, 16, 0, 0, SV_PE, 4, 0, 0},                  // 0: pts_linears.0
+    {1, 16, 0, 0, SV_H0 + 0, 16, 0, 0},             // 1: pts_linears.1
+    {2, 16, 0, 0, SV_H0 + 1, 16, 0, 0},             // 2
+    {3, 16, 0, 0, SV_H0 + 2, 16, 0, 0},             // 3
+    {4, 16, 0, 0, SV_H0 + 3, 16, 0, 0},             // 4
+    {5, 16, 0, 0, SV_H0 + 4, 16, SV_PE, 4},         // 5: pts_linears.5: columns [H4 | PE]
+    {6, 16, 0, 0, SV_H0 + 5, 16, 0, 0},             // 6: pts_linears.6
+    {7, 16, 0, 0, SV_H0 + 6, 16, 0, 0},             // 7: pts_linears.7
+    // 8: rows [dZ9 | d sigma] x columns [H7 | VPE]: P = dZ9^T H7 and sum dZ9 (feature_linear and
+    //    rgb_layers.0[:, :256], factored), sigma_linear (row 128), rgb_layers.0[:, 256:]
+    {9, 8, 8, 1, SV_H0 + 7, 16, SV_VPE, 2},
+    {10, 1, 0, 0, SV_G, 8, 0, 0},                   // 9: rgb_layers.2 (rows 0..2)
 };
-// partial block of GEMM g: [a_nks*16][b_nks*16] floats, then a_nks*16 bias floats
-constexpr int gemm_out_floats(int g) { return GEMMS[g].a_nks * 16 * GEMMS[g].b_nks * 16 + GEMMS[g].a_nks * 16; }
+constexpr int gemm_a_nks(int g) { return GEMMS[g].a_nks + GEMMS[g].a2_nks; }
+constexpr int gemm_b_nks(int g) { return GEMMS[g].b_nks + GEMMS[g].b2_nks; }
+// partial block of GEMM g: [rows][cols] floats, then one bias sum per row
+constexpr int gemm_out_floats(int g) { return gemm_a_nks(g) * 16 * gemm_b_nks(g) * 16 + gemm_a_nks(g) * 16; }
 constexpr int gemm_out_off(int g) { int o = 0; for (int i = 0; i < g; ++i) o += gemm_out_floats(i); return o; }
-constexpr int gemm_stage_kb(int g) { return GEMMS[g].a_nks + GEMMS[g].b_nks; }
+constexpr int gemm_stage_kb(int g) { return gemm_a_nks(g) + gemm_b_nks(g); }
 constexpr int TOTAL_STAGE_KB = [] { int s = 0; for (int g = 0; g < NGEMM; ++g) s += gemm_stage_kb(g); return s; }();
 
 constexpr int WGRAD_TARGET_JOBS = 256;     // one workgroup's worth of jobs per CU
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
 // 2. weight-gradient GEMMs
 // ------------------------------------------------------------------------------------------------
 constexpr int WG_STAGES = 4;                  // one being read, up to three in flight
-constexpr int WG_STAGE_BYTES = 32 * 1024;     // up to 16 A units + 16 B units
+constexpr int WG_STAGE_BYTES = 36 * 1024;     // up to 36 units: A units first, B units right behind them
 #ifndef NERF_WG_DMA_AUX
 #define NERF_WG_DMA_AUX 2
 #endif
@@ -349,22 +354,29 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
 
     // staging: unit u of a stage (A units first, then B units) is copied by wave u % 8
     constexpr int N_UNITS = A_NKS + B_NKS;
-    const int my_units = (N_UNITS - wave + 7) >> 3;       // 0..4
-    const char* a_src = a.dz + ((size_t)dz_ks0(gd.dz_layer) * a.n_wt) * 1024 + (size_t)gd.a_ks0 * 1024;
-    const size_t a_stride = (size_t)DZ_KS[gd.dz_layer] * 1024;          // bytes per wave tile
-    const char* b_src = a.saved + ((size_t)saved_ks0(gd.b_tensor) * a.n_wt) * 1024;
-    constexpr size_t b_stride = (size_t)B_NKS * 1024;
+    static_assert(N_UNITS * 1024 <= WG_STAGE_BYTES && N_UNITS <= 40, "stage size");
+    const int my_units = (N_UNITS - wave + 7) >> 3;       // 0..5
+    // the four operand runs: base of wave tile 0, bytes per wave tile, first unit of the run in the stage
+    const int a1n = gd.a_nks, b1n = gd.b_nks;
+    const char* a1_src = a.dz + (size_t)dz_ks0(gd.a_layer) * a.n_wt * 1024;
+    const char* a2_src = a.dz + (size_t)dz_ks0(gd.a2_layer) * a.n_wt * 1024;
+    const char* b1_src = a.saved + (size_t)saved_ks0(gd.b_tensor) * a.n_wt * 1024;
+    const char* b2_src = a.saved + (size_t)saved_ks0(gd.b2_tensor) * a.n_wt * 1024;
+    const size_t a1_stride = (size_t)DZ_KS[gd.a_layer] * 1024, a2_stride = (size_t)DZ_KS[gd.a2_layer] * 1024;
+    const size_t b1_stride = (size_t)SAVED_KS[gd.b_tensor] * 1024, b2_stride = (size_t)SAVED_KS[gd.b2_tensor] * 1024;
 
     auto issue = [&](int step, int stage) {
         const int64_t wt = wt0 + step;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 5; ++i) {
             const int u = wave + 8 * i;
             if (u < N_UNITS) {
-                const bool is_a = u < A_NKS;
-                const char* src = is_a ? a_src + (size_t)wt * a_stride + (size_t)u * 1024
-                                       : b_src + (size_t)wt * b_stride + (size_t)(u - A_NKS) * 1024;
-                char* dst = lds + stage * WG_STAGE_BYTES + (is_a ? u : 16 + (u - A_NKS)) * 1024;
+                const char* src;
+                if (u < a1n) src = a1_src + (size_t)wt * a1_stride + (size_t)u * 1024;
+                else if (u < A_NKS) src = a2_src + (size_t)wt * a2_stride + (size_t)(u - a1n) * 1024;
+                else if (u < A_NKS + b1n) src = b1_src + (size_t)wt * b1_stride + (size_t)(u - A_NKS) * 1024;
+                else src = b2_src + (size_t)wt * b2_stride + (size_t)(u - A_NKS - b1n) * 1024;
+                char* dst = lds + stage * WG_STAGE_BYTES + u * 1024;
                 __builtin_amdgcn_global_load_lds((gbl_char*)src + lane * 16, (lds_char*)dst, 16, 0, WG_DMA_AUX);
             }
         }
@@ -377,8 +389,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
         else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     };
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)((lds_char*)lds);   // LDS byte address of the staging area
@@ -395,7 +409,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int u = 2 * (TJ * wc + j) + (gg & 1);
-        b_unit[j] = lds_base + (16 + u) * 1024 + lane_rd;
+        b_unit[j] = lds_base + (A_NKS + u) * 1024 + lane_rd;
     }
 
     f32x16 acc[TI][TJ];
@@ -407,7 +421,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
     float bsum[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) bsum[i] = 0.f;
-    const bool do_bias = gd.has_bias && wc == 0;
+    const bool do_bias = wc == 0;
 
     if (nsteps > 0) issue(0, 0);
     if (nsteps > 1) issue(1, 1);
@@ -496,11 +510,10 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     int g = 0;
     while (g + 1 < NGEMM && (int)blockIdx.x >= a.jobs.job0[g + 1]) ++g;
     // shape dispatch (workgroup-uniform): <A units, B units, wave grid, tiles per wave>
-    if (g == 0 || g == 5) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, g, lds);
-    else if (g == 9) wgrad_body<PREC, 8, 16, 4, 2, 1, 4>(a, g, lds);
-    else if (g == 10) wgrad_body<PREC, 1, 16, 1, 8, 1, 1>(a, g, lds);
-    else if (g == 11) wgrad_body<PREC, 8, 2, 4, 1, 1, 1>(a, g, lds);
-    else if (g == 12) wgrad_body<PREC, 1, 8, 1, 4, 1, 1>(a, g, lds);
+    if (g == 0) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, g, lds);
+    else if (g == 5) wgrad_body<PREC, 16, 20, 4, 2, 2, 5>(a, g, lds);
+    else if (g == 8) wgrad_body<PREC, 9, 18, 2, 3, 3, 3>(a, g, lds);
+    else if (g == 9) wgrad_body<PREC, 1, 8, 1, 4, 1, 1>(a, g, lds);
     else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, g, lds);
 }
 
@@ -544,7 +557,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
     if (e >= N_PARAMS + PROD_FLOATS) return;
     if (e >= N_PARAMS) {                                // the product P, handed to mlp_post_kernel
         const int k = (e - N_PARAMS) >> 8, i = (e - N_PARAMS) & 255;
-        float v = sum_partials(a, 9, hidden_pos(k) * 256 + hidden_pos(i));
+        float v = sum_partials(a, 8, hidden_pos(k) * (gemm_b_nks(8) * 16) + hidden_pos(i));
         if (a.scale) v = v / *a.scale;
         a.prod[e - N_PARAMS] = v;
         return;
@@ -557,32 +570,34 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
         const int l = (e - OFF_W1) / (256 * 256 + 256), r = (e - OFF_W1) % (256 * 256 + 256);
         g = 1 + l;
         if (r < 65536) { row = hidden_pos(r >> 8); col = hidden_pos(r & 255); } else row = hidden_pos(r - 65536);
-    } else if (e < OFF_W6) {                            // pts_linears.5
+    } else if (e < OFF_W6) {                            // pts_linears.5: columns [H4 | PE]
+        g = 5;
         if (e < OFF_B5) {
             const int o = (e - OFF_W5) / 319, i = (e - OFF_W5) % 319;
             row = hidden_pos(o);
-            if (i < 63) { g = 5; col = pe_pos(i, 10); } else { g = 6; col = hidden_pos(i - 63); }
-        } else { g = 6; row = hidden_pos(e - OFF_B5); }
+            col = i < 63 ? 256 + pe_pos(i, 10) : hidden_pos(i - 63);
+        } else row = hidden_pos(e - OFF_B5);
     } else if (e < OFF_WS) {                            // pts_linears.6..7
         const int l = (e - OFF_W6) / (256 * 256 + 256), r = (e - OFF_W6) % (256 * 256 + 256);
-        g = 7 + l;
+        g = 6 + l;
         if (r < 65536) { row = hidden_pos(r >> 8); col = hidden_pos(r & 255); } else row = hidden_pos(r - 65536);
-    } else if (e < OFF_WF) {                            // sigma_linear
-        g = 10; row = 0;
+    } else if (e < OFF_WF) {                            // sigma_linear: row 128 of GEMM 8
+        g = 8; row = 128;
         if (e < OFF_BS) col = hidden_pos(e - OFF_WS);
     } else if (e < OFF_WR0) {                           // feature_linear: mlp_post_kernel
         return;
     } else if (e < OFF_WR2) {                           // rgb_layers.0
+        g = 8;
         if (e < OFF_BR0) {
             const int o = (e - OFF_WR0) / 283, i = (e - OFF_WR0) % 283;
             if (i < 256) return;                        // mlp_post_kernel
-            g = 11; row = hidden_pos(o); col = pe_pos(i - 256, 4);
-        } else { g = 9; row = hidden_pos(e - OFF_BR0); }
+            row = hidden_pos(o); col = 256 + pe_pos(i - 256, 4);
+        } else row = hidden_pos(e - OFF_BR0);
     } else {                                            // rgb_layers.2
-        g = 12;
+        g = 9;
         if (e < OFF_BR2) { row = (e - OFF_WR2) / 128; col = hidden_pos((e - OFF_WR2) % 128); } else row = e - OFF_BR2;
     }
-    const int R = GEMMS[g].a_nks * 16, C = GEMMS[g].b_nks * 16;
+    const int R = gemm_a_nks(g) * 16, C = gemm_b_nks(g) * 16;
     const int idx = col >= 0 ? row * C + col : R * C + row;
     float v = sum_partials(a, g, idx);
     if (a.scale) v = v / *a.scale;
