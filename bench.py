@@ -134,6 +134,40 @@ def render_section(mc, mf, pe, pv, device, args):
     return out
 
 
+def whole_frame_kernels(device):
+    """The bandwidth-bound kernels of the render path launched once over a whole 800x800 frame (640 000 rays)
+    instead of per chunk: with 1-3 GB per launch the launch ramp and the infinity cache no longer matter and the
+    rate is the kernel's own HBM rate.  Algorithmic bytes as in render_section; HIP events on the launch stream."""
+    from nerf_amd import ops
+    n = 640000
+    out = {}
+
+    def rate(fn, nbytes, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        gbs = nbytes / us / 1e3
+        return {"avg_us": round(us, 1), "bytes_per_launch": nbytes, "GB/s": round(gbs, 1),
+                "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+
+    with torch.no_grad():
+        for S in (64, 192):
+            raw = torch.randn(n, S, 4, device=device)
+            z = 2.0 + torch.cumsum(torch.rand(n, S, device=device), dim=-1) * (4.0 / S)     # increasing depths
+            out["composite_fwd_S%d" % S] = rate(lambda: ops.composite(raw, z, False), n * (28 * S + 24))
+            del raw, z
+        c2w = torch.eye(4, device=device)[:3].contiguous()
+        out["get_rays_800x800"] = rate(lambda: ops.get_rays(800, 800, 1111.0, c2w), n * 24, iters=20)
+        out["get_rays_3200x3200"] = rate(lambda: ops.get_rays(3200, 3200, 4444.0, c2w), 16 * n * 24)
+    return out
+
+
 def one_eighth_gpu(args):
     """The same bench restricted to 32 of the 256 CUs (HSA_CU_MASK=0:0-31 in a child process, which must
     be set before the runtime starts): the headline metric is also quoted "at 1/8 GPU".  Returns a summary, or a
@@ -309,6 +343,7 @@ def main():
         }
         if world == 1 and not args.no_render:
             out["render"] = render_section(mc, mf, pe, pv, device, args)
+            out["whole_frame_kernels"] = whole_frame_kernels(device)
         if world == 1 and not args.no_one_eighth:
             out["one_eighth_gpu"] = one_eighth_gpu(args)
         if world == 1 and not args.no_cpu_baseline:

@@ -40,45 +40,73 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ---- wave-level primitives (64 lanes) ------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane moves on the VALU's DPP path (no LDS traffic).  CTRL is the dpp_ctrl code: 0x110+n = row_shr:n,
+// 0x100+n = row_shl:n (rows are 16 lanes), 0x130 / 0x138 = wave_shl:1 / wave_shr:1, 0x142 / 0x143 =
+// row_bcast:15 / row_bcast:31 (last lane of a row, or of the lower half, to every lane above it).  A lane
+// whose source lies outside its row (or the wave), or whose row ROWS masks out, receives `old`.
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROWS, 0xf, false));
+}
+
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double dpp_move(double old, double v) {
+    const long long o = __builtin_bit_cast(long long, old), x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)o, (int)x, CTRL, ROWS, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, ROWS, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float read_lane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__device__ __forceinline__ double read_lane(double v, int l) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)x, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(x >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Inclusive prefix scans over the 64 lanes: Kogge-Stone inside each 16-lane row, then the row totals
+// carried upwards with the two row broadcasts.
+__device__ __forceinline__ float wave_incl_sum(float v) {
+    v += dpp_move<0x111>(0.0f, v); v += dpp_move<0x112>(0.0f, v);
+    v += dpp_move<0x114>(0.0f, v); v += dpp_move<0x118>(0.0f, v);
+    v += dpp_move<0x142, 0xa>(0.0f, v);
+    v += dpp_move<0x143, 0xc>(0.0f, v);
     return v;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ double wave_incl_sum(double v) {
+    v += dpp_move<0x111>(0.0, v); v += dpp_move<0x112>(0.0, v);
+    v += dpp_move<0x114>(0.0, v); v += dpp_move<0x118>(0.0, v);
+    v += dpp_move<0x142, 0xa>(0.0, v);
+    v += dpp_move<0x143, 0xc>(0.0, v);
     return v;
 }
 
-// inclusive prefix product over the 64 lanes (Hillis-Steele on shuffles)
-__device__ __forceinline__ double wave_incl_prod(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double t = __shfl_up(v, o, 64);
-        if (lane >= o) v *= t;
-    }
+__device__ __forceinline__ double wave_incl_prod(double v) {
+    v *= dpp_move<0x111>(1.0, v); v *= dpp_move<0x112>(1.0, v);
+    v *= dpp_move<0x114>(1.0, v); v *= dpp_move<0x118>(1.0, v);
+    v *= dpp_move<0x142, 0xa>(1.0, v);
+    v *= dpp_move<0x143, 0xc>(1.0, v);
     return v;
 }
 
-__device__ __forceinline__ double wave_incl_sum(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
+// sum over the wave, the same value on every lane
+__device__ __forceinline__ float wave_sum(float v) { return read_lane(wave_incl_sum(v), 63); }
+__device__ __forceinline__ double wave_sum(double v) { return read_lane(wave_incl_sum(v), 63); }
 
-// inclusive SUFFIX sum: lane l gets sum_{j >= l} v_j
+// inclusive SUFFIX sum: lane l gets sum_{j >= l} v_j (suffix scan inside each row, then the totals of the
+// rows above, read from their first lanes)
 __device__ __forceinline__ float wave_incl_suffix_sum(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float t = __shfl_down(v, o, 64);
-        if (lane + o < 64) v += t;
-    }
-    return v;
+    v += dpp_move<0x101>(0.0f, v); v += dpp_move<0x102>(0.0f, v);
+    v += dpp_move<0x104>(0.0f, v); v += dpp_move<0x108>(0.0f, v);
+    const float t1 = read_lane(v, 16), t2 = read_lane(v, 32), t3 = read_lane(v, 48);
+    const int row = lane >> 4;
+    const float above = row == 0 ? t1 + (t2 + t3) : (row == 1 ? t2 + t3 : (row == 2 ? t3 : 0.0f));
+    return v + above;
 }
 
 }  // namespace nerf

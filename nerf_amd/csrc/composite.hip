@@ -6,7 +6,9 @@
 // product scan across the wave, carried from chunk to chunk; it is evaluated
 // in fp64 and rounded to fp32 per element, which is what the reference's CPU
 // cumprod does.  The backward recomputes the forward quantities from (raw, z)
-// and needs one reverse (suffix) sum scan of G_j * w_j.
+// and needs one reverse (suffix) sum scan of G_j * w_j.  All scans and sums move
+// data between lanes with DPP modifiers on the VALU (nothing goes through LDS);
+// the forward is bound by HBM once exp and sigmoid use the hardware exp2 / rcp.
 // Compiled with -ffp-contract=off.
 #include "common.hpp"
 
@@ -17,23 +19,26 @@ struct SampleFwd {
     float cr, cg, cb;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp and sigmoid on the hardware exp2 / rcp units (1 ulp each).  The argument's rounding after the scaling
+// by log2(e) adds a relative error of about 1e-7 * |x|, which exp(x) <= 1 and s(1-s) keep below 1e-7
+// absolute in alpha and in the colours.
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_hw(-x)); }
 
 // forward quantities of one chunk; `carry` is the running product of q over earlier chunks
 __device__ __forceinline__ SampleFwd chunk_forward(const float4 r, float zk, float zn, bool valid, bool last,
-                                                   int lane, double& carry) {
+                                                   double& carry) {
     SampleFwd s;
     const float dist = last ? 1e10f : zn - zk;
     const float sig = fmaxf(r.w, 0.0f);
-    const float e = expf(-sig * dist);
+    const float e = exp_hw(-sig * dist);
     s.alpha = valid ? 1.0f - e : 0.0f;
     s.de = valid ? dist * e : 0.0f;
     s.q = (1.0f - s.alpha) + 1e-10f;
-    const double incl = wave_incl_prod(valid ? (double)s.q : 1.0, lane);
-    double excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 1.0;
+    const double incl = wave_incl_prod(valid ? (double)s.q : 1.0);
+    const double excl = dpp_move<0x138>(1.0, incl);        // lane k-1's product; 1 on lane 0
     s.T = (float)(carry * excl);
-    carry = carry * __shfl(incl, 63, 64);
+    carry = carry * read_lane(incl, 63);
     s.w = s.alpha * s.T;
     s.cr = sigmoidf_(r.x); s.cg = sigmoidf_(r.y); s.cb = sigmoidf_(r.z);
     return s;
@@ -46,7 +51,47 @@ __device__ __forceinline__ float disp_of(float depth, float acc) {
     return d;
 }
 
-// NCH > 0: chunks unrolled (S <= 64*NCH); NCH == 0: run-time chunk loop.
+// The (rgb, sigma) records and depths of one ray, sample 64c + lane in element c.
+template <int NCH>
+struct RayRecords {
+    float4 r[NCH];
+    float z[NCH];
+};
+
+// Every lane always issues its loads (lanes past the last sample re-read it), so the number of loads in
+// flight is fixed and the waits on them can be counted.  Records are read once and results written once:
+// both go past the caches as streaming (non-temporal) accesses.
+template <int NCH>
+__device__ __forceinline__ void load_ray(RayRecords<NCH>& in, const float4* __restrict__ raw, const float* __restrict__ z,
+                                         int64_t base, int S, int lane) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = min(c * 64 + lane, S - 1);
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(raw + base + k));
+        in.r[c] = make_float4(v.x, v.y, v.z, v.w);
+        in.z[c] = __builtin_nontemporal_load(z + base + k);
+    }
+}
+
+struct RaySums {
+    float r, g, b, d, a;
+};
+
+__device__ __forceinline__ void store_maps(const RaySums& t, int64_t ray, int white, int lane, float* __restrict__ rgb_map,
+                                           float* __restrict__ depth_map, float* __restrict__ disp_map,
+                                           float* __restrict__ acc_map) {
+    const float sr = wave_sum(t.r), sg = wave_sum(t.g), sb = wave_sum(t.b), sd = wave_sum(t.d), sa = wave_sum(t.a);
+    if (lane == 0) {
+        const float bg = white ? 1.0f - sa : 0.0f;
+        rgb_map[3 * ray + 0] = sr + bg; rgb_map[3 * ray + 1] = sg + bg; rgb_map[3 * ray + 2] = sb + bg;
+        depth_map[ray] = sd; acc_map[ray] = sa; disp_map[ray] = disp_of(sd, sa);
+    }
+}
+
+// S <= 64*NCH.  Each wave walks its rays with the next ray's records already in flight while the current
+// one is scanned, so a resident wave always has loads outstanding; the grid is sized to one full set of
+// resident waves (see ray_grid_fwd).
 template <int NCH>
 __global__ __launch_bounds__(256) void composite_fwd_kernel(int64_t n_rays, int S, const float4* __restrict__ raw,
                                                             const float* __restrict__ z, int white,
@@ -57,49 +102,68 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(int64_t n_rays, int 
                                                             float* __restrict__ weights,
                                                             float* __restrict__ alpha_out) {
     const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    if (wave0 >= n_rays) return;
+    RayRecords<NCH> cur, nxt;
+    load_ray(cur, raw, z, wave0 * S, S, lane);
+    for (int64_t ray = wave0; ray < n_rays; ray += nwaves) {
+        const int64_t base = ray * S;
+        load_ray(nxt, raw, z, min(ray + nwaves, n_rays - 1) * S, S, lane);   // the last round re-reads a ray
+        double carry = 1.0;
+        RaySums t = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            const bool valid = k < S;
+            // depth of sample k+1: the lane above, or lane 0 of the next chunk
+            float zn = dpp_move<0x130>(0.0f, cur.z[c]);
+            if (c + 1 < NCH) { const float first = read_lane(cur.z[c + 1], 0); if (lane == 63) zn = first; }
+            const SampleFwd s = chunk_forward(cur.r[c], cur.z[c], zn, valid, k == S - 1, carry);
+            if (valid) {
+                __builtin_nontemporal_store(s.w, weights + base + k);
+                if (alpha_out) __builtin_nontemporal_store(s.alpha, alpha_out + base + k);
+            }
+            t.r += s.w * s.cr; t.g += s.w * s.cg; t.b += s.w * s.cb;
+            t.d += s.w * cur.z[c]; t.a += s.w;
+        }
+        store_maps(t, ray, white, lane, rgb_map, depth_map, disp_map, acc_map);
+        cur = nxt;
+    }
+}
+
+// Any S: run-time chunk loop, one ray per wave at a time.
+__global__ __launch_bounds__(256) void composite_fwd_long_kernel(int64_t n_rays, int S, const float4* __restrict__ raw,
+                                                                 const float* __restrict__ z, int white,
+                                                                 float* __restrict__ rgb_map,
+                                                                 float* __restrict__ depth_map,
+                                                                 float* __restrict__ disp_map,
+                                                                 float* __restrict__ acc_map,
+                                                                 float* __restrict__ weights,
+                                                                 float* __restrict__ alpha_out) {
+    const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int nch = NCH > 0 ? NCH : (S + 63) >> 6;
+    const int nch = (S + 63) >> 6;
     for (int64_t ray = wave0; ray < n_rays; ray += nwaves) {
         const int64_t base = ray * S;
         double carry = 1.0;
-        float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
-        float4 r[NCH > 0 ? NCH : 1];
-        float zk[NCH > 0 ? NCH : 1], zn[NCH > 0 ? NCH : 1];
-        if (NCH > 0) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int k = c * 64 + lane;
-                r[c] = k < S ? raw[base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                zk[c] = k < S ? z[base + k] : 0.f;
-                zn[c] = k + 1 < S ? z[base + k + 1] : 0.f;
-            }
-        }
-#pragma unroll
+        RaySums t = {0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < nch; ++c) {
             const int k = c * 64 + lane;
             const bool valid = k < S;
-            float4 rc; float zkc, znc;
-            if (NCH > 0) { rc = r[c]; zkc = zk[c]; znc = zn[c]; }
-            else {
-                rc = valid ? raw[base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                zkc = valid ? z[base + k] : 0.f;
-                znc = k + 1 < S ? z[base + k + 1] : 0.f;
-            }
-            const SampleFwd s = chunk_forward(rc, zkc, znc, valid, k == S - 1, lane, carry);
+            const float4 rc = valid ? raw[base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float zk = valid ? z[base + k] : 0.f;
+            const float zn = k + 1 < S ? z[base + k + 1] : 0.f;
+            const SampleFwd s = chunk_forward(rc, zk, zn, valid, k == S - 1, carry);
             if (valid) {
                 weights[base + k] = s.w;
                 if (alpha_out) alpha_out[base + k] = s.alpha;
             }
-            sr += s.w * s.cr; sg += s.w * s.cg; sb += s.w * s.cb;
-            sd += s.w * zkc; sa += s.w;
+            t.r += s.w * s.cr; t.g += s.w * s.cg; t.b += s.w * s.cb;
+            t.d += s.w * zk; t.a += s.w;
         }
-        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
-        if (lane == 0) {
-            const float bg = white ? 1.0f - sa : 0.0f;
-            rgb_map[3 * ray + 0] = sr + bg; rgb_map[3 * ray + 1] = sg + bg; rgb_map[3 * ray + 2] = sb + bg;
-            depth_map[ray] = sd; acc_map[ray] = sa; disp_map[ray] = disp_of(sd, sa);
-        }
+        store_maps(t, ray, white, lane, rgb_map, depth_map, disp_map, acc_map);
     }
 }
 
@@ -130,7 +194,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n_rays, int 
             zk[c] = valid ? z[base + k] : 0.f;
             const float zn = k + 1 < S ? z[base + k + 1] : 0.f;
             rawsig[c] = rc.w;
-            s[c] = chunk_forward(rc, zk[c], zn, valid, k == S - 1, lane, carry);
+            s[c] = chunk_forward(rc, zk[c], zn, valid, k == S - 1, carry);
             sd += s[c].w * zk[c]; sa += s[c].w;
         }
         float gr = 0.f, gg = 0.f, gb = 0.f;
@@ -159,7 +223,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n_rays, int 
             const float gw = valid ? G * v.w : 0.f;
             const float incl = wave_incl_suffix_sum(gw, lane);
             const float after = (incl - gw) + suffix_carry;   // sum_{j>k} G_j w_j
-            suffix_carry += __shfl(incl, 0, 64);
+            suffix_carry += read_lane(incl, 0);
             float dalpha = G * v.T - after / v.q;
             if (g_alpha && valid) dalpha += g_alpha[base + k];
             const float dsig = rawsig[c] > 0.0f ? dalpha * v.de : 0.0f;
@@ -173,6 +237,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n_rays, int 
             }
         }
     }
+}
+
+// forward: 8 blocks of 4 waves per CU keep all 256 CUs full (the kernels stay under 64 VGPRs); each wave
+// then walks n_rays / 8192 rays
+static inline unsigned ray_grid_fwd(int64_t n_rays) {
+    int64_t blocks = (n_rays + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    return (unsigned)blocks;
 }
 
 static inline unsigned ray_grid(int64_t n_rays) {
@@ -191,18 +263,18 @@ extern "C" int nerf_composite_fwd(int64_t n_rays, int S, const float* raw, const
     NERF_REQUIRE(raw && z && rgb_map && depth_map && disp_map && acc_map && weights, NERF_E_NULL);
     NERF_REQUIRE(nerf_aligned(raw, 16), NERF_E_ALIGN);
     if (n_rays == 0) return NERF_OK;
-    const dim3 grid(nerf::ray_grid(n_rays)), block(256);
+    const dim3 grid(nerf::ray_grid_fwd(n_rays)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const float4* r4 = reinterpret_cast<const float4*>(raw);
-#define NERF_FWD(N)                                                                                        \
-    hipLaunchKernelGGL(nerf::composite_fwd_kernel<N>, grid, block, 0, st, n_rays, S, r4, z, white_bkgd,    \
-                       rgb_map, depth_map, disp_map, acc_map, weights, alpha)
+#define NERF_FWD(K)                                                                                        \
+    hipLaunchKernelGGL(nerf::K, grid, block, 0, st, n_rays, S, r4, z, white_bkgd, rgb_map, depth_map,      \
+                       disp_map, acc_map, weights, alpha)
     const int nch = (S + 63) / 64;
-    if (nch == 1) NERF_FWD(1);
-    else if (nch == 2) NERF_FWD(2);
-    else if (nch == 3) NERF_FWD(3);
-    else if (nch == 4) NERF_FWD(4);
-    else NERF_FWD(0);
+    if (nch == 1) NERF_FWD(composite_fwd_kernel<1>);
+    else if (nch == 2) NERF_FWD(composite_fwd_kernel<2>);
+    else if (nch == 3) NERF_FWD(composite_fwd_kernel<3>);
+    else if (nch == 4) NERF_FWD(composite_fwd_kernel<4>);
+    else NERF_FWD(composite_fwd_long_kernel);
 #undef NERF_FWD
     return nerf_launch_status();
 }

@@ -25,9 +25,9 @@ __device__ __forceinline__ void build_cdf(WeightFn weight, int n_w, float* __res
     for (int i0 = 0; i0 < n_w; i0 += 64) {
         const int i = i0 + lane;
         const float pdf = i < n_w ? __fdiv_rn(weight(i) + 1e-5f, total) : 0.0f;
-        const double incl = wave_incl_sum((double)pdf, lane);
+        const double incl = wave_incl_sum((double)pdf);
         if (i < n_w) cdf[i + 1] = (float)(carry + incl);                        // nerf.py:243
-        carry += __shfl(incl, 63, 64);
+        carry += read_lane(incl, 63);
     }
 }
 
