@@ -254,6 +254,11 @@ def main():
     step_fn = TrainStep(mc, mf, pe, pv, opt, n, near=2.0, far=6.0, N_samples_coarse=64, N_samples_fine=128,
                         world_size=world, use_graph=not args.no_graph)
 
+    # the batch sits in the step's own input buffers, where a loader's gather kernel writes it
+    # (Trainer.train_step), so a step issues no input copies
+    step_fn.rays_o.copy_(rays_o); step_fn.rays_d.copy_(rays_d); step_fn.target.copy_(target)
+    rays_o, rays_d, target = step_fn.rays_o, step_fn.rays_d, step_fn.target
+
     def lr_at(i):      # scripts/train_nerf.py:288: lr0 * decay^(step / decay_steps)
         return 5e-4 * (0.1 ** (i / 250000.0))
 
@@ -338,7 +343,8 @@ def main():
                                    "NeRF, fwd+bwd+Adam (benchmark configuration: single training step, batch 1024 rays)" % n,
                        "rays_per_gpu": n, "global_rays": n * world, "samples_per_ray": "64+192 evaluations",
                        "parallelism": "dp%d" % world if world > 1 else "single"},
-            "launch_mode": "eager" if args.no_graph else "hipgraph replay (2 graphs per step)",
+            "launch_mode": "eager" if args.no_graph else ("hipgraph replay (one graph per step)" if world == 1 else
+                                                         "hipgraph replay (2 graphs per step, all-reduce between)"),
             "roofline": roofline, "kernels": kernels,
         }
         if world == 1 and not args.no_render:

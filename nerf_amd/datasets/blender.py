@@ -94,14 +94,16 @@ class BlenderDataset:
         return ops.gather_rays(pix, self.height, self.width, self.focal, self.poses, self.images, self._lut,
                                self.data_white_bkgd)
 
-    def sample_rays(self, n: int, generator: Optional[torch.Generator] = None, rank: int = 0, world_size: int = 1):
+    def sample_rays(self, n: int, generator: Optional[torch.Generator] = None, rank: int = 0, world_size: int = 1,
+                    out=None):
         """n rays drawn uniformly (with replacement) over every pixel of every image.  With
         ``world_size`` > 1 all ranks must pass generators in the same state: one draw of
-        n*world_size ids is made and rank r keeps its slice, so ranks see disjoint parts of one batch."""
+        n*world_size ids is made and rank r keeps its slice, so ranks see disjoint parts of one batch.
+        ``out`` = (rays_o, rays_d, target) receives the batch in place (a training step's input buffers)."""
         total = n * world_size
         pix = torch.randint(0, self.num_rays, (total,), device=self.device, generator=generator)
         return ops.gather_rays(pix[rank * n:(rank + 1) * n], self.height, self.width, self.focal, self.poses,
-                               self.images, self._lut, self.data_white_bkgd)
+                               self.images, self._lut, self.data_white_bkgd, out=out)
 
     # -- the reference's per-image view -------------------------------------------------------------
     def image_rgb(self, idx: int) -> torch.Tensor:

@@ -80,9 +80,10 @@ def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor, row0: int = 0,
 
 def gather_rays(pix: torch.Tensor, H: int, W: int, focal: float, poses: torch.Tensor,
                 images: Optional[torch.Tensor] = None, lut: Optional[torch.Tensor] = None,
-                white_bkgd: bool = False):
+                white_bkgd: bool = False, out: Optional[Sequence[torch.Tensor]] = None):
     """Rays (and blended target colours when ``images`` is given) of the global pixel ids ``pix``
-    (image*H*W + y*W + x) of an image bank: (rays_o, rays_d, target or None), each [n, 3]."""
+    (image*H*W + y*W + x) of an image bank: (rays_o, rays_d, target or None), each [n, 3].
+    ``out`` = (rays_o, rays_d, target) writes into existing contiguous fp32 [n, 3] tensors instead."""
     poses = _gpu_f32(poses, "poses")
     if poses.dim() != 3 or poses.shape[1] not in (3, 4) or poses.shape[2] != 4:
         raise ValueError(f"poses must be [n_images, 4, 4] or [n_images, 3, 4], got {tuple(poses.shape)}")
@@ -91,8 +92,15 @@ def gather_rays(pix: torch.Tensor, H: int, W: int, focal: float, poses: torch.Te
         raise RuntimeError("pix must be a 1-D int64 tensor on the poses' device")
     pix = pix.contiguous()
     n, n_img = pix.numel(), poses.shape[0]
-    ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    if out is not None:
+        for t in out:
+            if t is not None and (t.device != dev or t.dtype != torch.float32 or tuple(t.shape) != (n, 3)
+                                  or not t.is_contiguous()):
+                raise RuntimeError(f"out tensors must be contiguous fp32 [{n}, 3] on the poses' device")
+        ro, rd = out[0], out[1]
+    else:
+        ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
     tgt, C = None, 0
     if images is not None:
         if (images.device != dev or images.dtype != torch.uint8 or images.dim() != 4 or not images.is_contiguous()
@@ -102,7 +110,9 @@ def gather_rays(pix: torch.Tensor, H: int, W: int, focal: float, poses: torch.Te
         if lut.numel() != 256:
             raise ValueError("lut must hold 256 floats")
         C = images.shape[3]
-        tgt = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        tgt = out[2] if out is not None else torch.empty((n, 3), dtype=torch.float32, device=dev)
+        if tgt is None:
+            raise RuntimeError("out[2] is needed for the target colours")
     with torch.cuda.device(dev):
         check(lib.nerf_gather_rays(n, _p(pix), n_img, int(H), int(W), float(focal), _p(poses),
                                    poses.shape[1] * 4, _p(images), C, _p(lut), int(bool(white_bkgd)), _p(ro), _p(rd),
@@ -241,6 +251,25 @@ def mse_pair(rgb_coarse: torch.Tensor, rgb_fine: torch.Tensor, target: torch.Ten
     """Both photometric losses and their sum in one launch: (total, loss_coarse, loss_fine), scalars
     that are views of one 3-float tensor (``out`` if given).  Gradients flow through ``total``."""
     return _MsePair.apply(rgb_coarse, rgb_fine, target, out)
+
+
+@torch.no_grad()
+def mse_pair_grads(rgb_coarse: torch.Tensor, rgb_fine: torch.Tensor, target: torch.Tensor,
+                   out: Optional[torch.Tensor] = None):
+    """The same launch outside autograd: ((total, loss_coarse, loss_fine), d total/d rgb_coarse,
+    d total/d rgb_fine).  ``torch.autograd.backward([rgb_coarse, rgb_fine], [d_coarse, d_fine])`` is then
+    ``total.backward()`` without the unit root gradient and the two products with it."""
+    a, b, target = _gpu_f32(rgb_coarse, "rgb_coarse"), _gpu_f32(rgb_fine, "rgb_fine"), _gpu_f32(target, "target_rgb")
+    if a.shape != target.shape or b.shape != target.shape:
+        raise ValueError(f"rgb maps and target must agree in shape: {tuple(a.shape)}, {tuple(b.shape)}, "
+                         f"{tuple(target.shape)}")
+    dev = a.device
+    losses = out if out is not None else torch.empty((3,), dtype=torch.float32, device=dev)
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    with torch.cuda.device(dev):
+        check(lib.nerf_mse_pair(a.numel(), _p(a), _p(b), _p(target), _p(losses), _p(da), _p(db), _stream(dev)),
+              "nerf_mse_pair")
+    return (losses[0], losses[1], losses[2]), da, db
 
 
 def composite(raw: torch.Tensor, z_vals: torch.Tensor, white_bkgd: bool = False):

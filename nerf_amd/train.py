@@ -5,7 +5,12 @@ the bottleneck.  ``TrainStep`` runs the same call sequence eagerly or captures i
 graphs (forward + backward + gradient bucket; optimizer) and replays them, with the inputs in
 static buffers and the optimizer's hyper-parameters in device memory so that the learning rate can
 change between replays.  Between the two graphs sits the only collective of data-parallel
-training, one summing all-reduce of the flat gradient bucket.
+training, one summing all-reduce of the flat gradient bucket; a single process has no collective and
+captures the whole step as one graph (a graph boundary idles the GPU for about 9 us).
+
+The static input buffers are ``TrainStep.rays_o / rays_d / target``: a producer that writes a batch
+straight into them (``BlenderDataset.sample_rays(out=...)``) and passes those same tensors to the
+call skips the three device copies.
 """
 from __future__ import annotations
 
@@ -48,9 +53,11 @@ class TrainStep:
         coarse, fine = render_hierarchical(self.mc, self.mf, self.pe, self.pv, self.rays_o, self.rays_d, self.near,
                                            self.far, self.nc, self.nf, rand=True, det=False, lindisp=self.lindisp,
                                            white_bkgd=self.white, t_rand_coarse=t_c, u_fine=u_f, t_rand_fine=t_f)
-        total, _, _ = ops.mse_pair(coarse["rgb_map"], fine["rgb_map"], self.target, out=self.losses)
+        # loss.backward() of train_nerf.py:334 with the unit root gradient folded away: the loss kernel
+        # hands back d loss / d rgb of both maps, which seed the backward pass directly
+        _, d_coarse, d_fine = ops.mse_pair_grads(coarse["rgb_map"], fine["rgb_map"], self.target, out=self.losses)
         self.opt.zero_grad(set_to_none=True)
-        total.backward()
+        torch.autograd.backward([coarse["rgb_map"], fine["rgb_map"]], [d_coarse, d_fine])
         self.opt.gather_grads()
 
     def _optimizer(self):
@@ -67,9 +74,12 @@ class TrainStep:
         self._g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fb):
             self._forward_backward()
-        self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt):
-            self._optimizer()
+            if self.world == 1:
+                self._optimizer()
+        if self.world > 1:
+            self._g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_opt):
+                self._optimizer()
         # capture only records: nothing ran, so neither the weights nor the step counter moved
 
     def prepare(self) -> None:
@@ -81,9 +91,9 @@ class TrainStep:
     def __call__(self, rays_o: torch.Tensor, rays_d: torch.Tensor, target_rgb: torch.Tensor,
                  lr: Optional[float] = None) -> torch.Tensor:
         """One optimisation step on this rank's rays; returns the (device) total loss of this rank."""
-        self.rays_o.copy_(rays_o, non_blocking=True)
-        self.rays_d.copy_(rays_d, non_blocking=True)
-        self.target.copy_(target_rgb, non_blocking=True)
+        for dst, src in ((self.rays_o, rays_o), (self.rays_d, rays_d), (self.target, target_rgb)):
+            if src is not dst:
+                dst.copy_(src, non_blocking=True)
         if lr is not None:
             self.opt.param_groups[0]["lr"] = lr
             self.opt.device_state()[0:1].fill_(lr)
@@ -91,8 +101,9 @@ class TrainStep:
             if self._g_fb is None:
                 self._capture()
             self._g_fb.replay()
-            allreduce_gradients_(self.opt.flat_grad, self.world)
-            self._g_opt.replay()
+            if self._g_opt is not None:
+                allreduce_gradients_(self.opt.flat_grad, self.world)
+                self._g_opt.replay()
         else:
             self._forward_backward()
             allreduce_gradients_(self.opt.flat_grad, self.world)

@@ -4,7 +4,7 @@ The reference's DataLoader hands the step ``batch_size`` *images* worth of rays 
 ``--batch_size`` is documented as "number of rays per batch" (train_nerf.py:67, :163, :280-283).  This
 trainer does what the option says: every step draws ``batch_rays`` pixels uniformly over all training
 images (on the GPU, ``BlenderDataset.sample_rays``), runs the coarse + fine step
-(train_nerf.py:293-336) from two HIP graphs, decays the learning rate per global step (:288-290), logs
+(train_nerf.py:293-336) from HIP graphs, decays the learning rate per global step (:288-290), logs
 every ``log_freq`` steps (:342-357) and writes checkpoints in the reference's format (:109-137).
 An "epoch" keeps the reference's meaning of one pass over the data: ceil(total rays / batch_rays) steps.
 """
@@ -96,7 +96,9 @@ class Trainer:
 
     # -- one optimisation step (train_nerf.py:280-339) -------------------------------------------------
     def train_step(self) -> torch.Tensor:
-        rays_o, rays_d, target = self.data.sample_rays(self.cfg.batch_size, self.sampler, self.rank, self.world)
+        step = self.step_fn       # the batch is gathered straight into the step's input buffers
+        rays_o, rays_d, target = self.data.sample_rays(self.cfg.batch_size, self.sampler, self.rank, self.world,
+                                                       out=(step.rays_o, step.rays_d, step.target))
         lr = learning_rate(self.cfg, self.global_step)
         loss = self.step_fn(rays_o, rays_d, target, lr=lr)
         self.global_step += 1
