@@ -70,6 +70,9 @@ def parse():
                          "4096 is the reference's eval_batch_size (render_nerf.py:55)")
     ap.add_argument("--no-one-eighth", action="store_true",
                     help="skip the 32-of-256-CU run (the metric's '1/8 GPU' reading), a child process under HSA_CU_MASK")
+    ap.add_argument("--dist-backend", default=None,
+                    help="torch.distributed backend (default: nccl = RCCL on GPUs); gloo lets several ranks share one GPU "
+                         "to rehearse the N>1 code path")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying HIP graphs")
     ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
     return ap.parse_args()
@@ -227,10 +230,19 @@ def cpu_baseline(n_rays, steps):
                       f"{threads} threads, after 1 warm-up step"}
 
 
+def stage(msg):
+    """Progress marker on stderr when NERF_BENCH_TRACE is set (to localise a hang in a multi-process run)."""
+    if os.environ.get("NERF_BENCH_TRACE"):
+        print("[bench rank %s] %.2f %s" % (os.environ.get("RANK", "0"), time.time() % 1000, msg), file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    if os.environ.get("NERF_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NERF_BENCH_TRACE"]), exit=False)     # where a hung rank is
     from nerf_amd.parallel import init_distributed
-    rank, world, local_rank = init_distributed()
+    rank, world, local_rank = init_distributed(args.dist_backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     device = torch.device("cuda", torch.cuda.current_device())
@@ -262,14 +274,19 @@ def main():
     def lr_at(i):      # scripts/train_nerf.py:288: lr0 * decay^(step / decay_steps)
         return 5e-4 * (0.1 ** (i / 250000.0))
 
+    stage("models built, parameters broadcast")
     for s in range(args.warmup):
         step_fn(rays_o, rays_d, target, lr=lr_at(s))
+        stage("warm-up step %d issued" % s)
     sync()
+    stage("warm-up done")
     t0 = time.perf_counter()
     for s in range(args.steps):
         loss = step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + s))
+        stage("timed step %d issued" % s)
     sync()
     dt = time.perf_counter() - t0
+    stage("timed region done")
     # per-kernel durations: the same step issued eagerly with HIP events on the launch stream
     step_fn.use_graph = False
     step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + args.steps))
@@ -279,9 +296,8 @@ def main():
     sync()
     times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from nerf_amd.parallel import all_reduce_
+        dt = float(all_reduce_(torch.tensor([dt], dtype=torch.float64, device=device), op=dist.ReduceOp.MAX).item())
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss")
 

@@ -52,9 +52,12 @@ def gather_rows(block: torch.Tensor, H: int, rank: int, world: int) -> torch.Ten
     max_rows = shard_rows(H, 0, world)[1]
     pad = torch.zeros((max_rows,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
     pad[: block.shape[0]] = block
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
-    return torch.cat([out[r][: shard_rows(H, r, world)[1]] for r in range(world)], dim=0)
+    staged = _host_staged(pad)
+    src = pad.cpu() if staged else pad
+    out = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(out, src)
+    frame = torch.cat([out[r][: shard_rows(H, r, world)[1]] for r in range(world)], dim=0)
+    return frame.to(block.device) if staged else frame
 
 
 def render_frame_sharded(render_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
@@ -74,15 +77,39 @@ def render_frame_sharded(render_fn: Callable[[torch.Tensor, torch.Tensor], torch
     return gather_rows(block, H, rank, world)
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo moves device tensors through pinned host copies on streams of its own; with several ranks
+    sharing one GPU (the only way to rehearse N > 1 on a one-GPU machine) that path stalls for seconds to
+    minutes, for any program.  Under gloo, device tensors are therefore staged through the host here."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
+    """In-place all-reduce of ``t`` (sum by default) on the default group."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def allreduce_gradients_(flat_grad: torch.Tensor, world: int) -> float:
     """Summing all-reduce of the gradient bucket in place; returns the factor the optimizer must
     apply (1/world) so that the update equals that of the global batch (equal shard sizes)."""
     if world > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        all_reduce_(flat_grad)
     return 1.0 / world
 
 
 def broadcast_parameters_(flat_params: torch.Tensor, world: int) -> None:
     """Make every rank start from rank 0's weights."""
     if world > 1:
-        dist.broadcast(flat_params, src=0)
+        if _host_staged(flat_params):
+            h = flat_params.cpu()
+            dist.broadcast(h, src=0)
+            flat_params.copy_(h)
+        else:
+            dist.broadcast(flat_params, src=0)

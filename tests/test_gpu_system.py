@@ -138,3 +138,31 @@ def test_render_path_and_evaluate(tmp_path):
     assert abs(ev["mse"][1] - mse) < 1e-7 and abs(ev["psnr"][1] + 10 * math.log10(mse)) < 1e-4
     part = evaluate(mc, mf, pe, pv, ds, rank=1, world_size=2, white_bkgd=True)
     assert sorted(part["psnr"]) == [1] and part["psnr"][1] == ev["psnr"][1]
+
+
+def test_two_rank_training_step_on_one_gpu(tmp_path):
+    """Data-parallel TrainStep with world_size 2 (two processes sharing this GPU, gloo): with the same rays,
+    targets and jitter on both ranks the summed-and-halved gradient is the single-process gradient bit for
+    bit, so the weights after three steps are identical to a single-process run; with different targets on
+    rank 1 both ranks still end with identical weights, which differ from the single-process ones."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from dp_gpu_worker import run_steps
+    single, single_losses = run_steps(1, 0, "same")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for mode, port in (("same", 29561), ("split", 29562)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(here, "dp_gpu_worker.py"), str(tmp_path), mode]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0, r.stderr[-2000:]
+        a = torch.load(tmp_path / f"{mode}_rank0.pt", weights_only=True)
+        b = torch.load(tmp_path / f"{mode}_rank1.pt", weights_only=True)
+        assert torch.equal(a["flat"], b["flat"]), "ranks diverged"
+        if mode == "same":
+            assert torch.equal(a["flat"], single) and a["losses"] == single_losses
+        else:
+            assert not torch.equal(a["flat"], single)
+            assert a["losses"][0] == single_losses[0] and b["losses"][0] != single_losses[0]
