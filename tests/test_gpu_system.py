@@ -152,8 +152,12 @@ def test_two_rank_training_step_on_one_gpu(tmp_path):
     sys.path.insert(0, here)
     from dp_gpu_worker import run_steps
     single, single_losses = run_steps(1, 0, "same")
+    import socket
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    for mode, port in (("same", 29561), ("split", 29562)):
+    for mode in ("same", "split"):
+        with socket.socket() as sk:                      # a port that is free right now
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(here, "dp_gpu_worker.py"), str(tmp_path), mode]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
