@@ -360,7 +360,8 @@ def main():
                        "rays_per_gpu": n, "global_rays": n * world, "samples_per_ray": "64+192 evaluations",
                        "parallelism": "dp%d" % world if world > 1 else "single"},
             "launch_mode": "eager" if args.no_graph else ("hipgraph replay (one graph per step)" if world == 1 else
-                                                         "hipgraph replay (2 graphs per step, all-reduce between)"),
+                                                         "hipgraph replay (3 graphs per step: the all-reduce of the fine network's gradients overlaps the "
+                                                         "coarse backward, the coarse half follows, then Adam)"),
             "roofline": roofline, "kernels": kernels,
         }
         if world == 1 and not args.no_render:

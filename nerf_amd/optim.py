@@ -8,7 +8,7 @@ gradient exchange is one all-reduce of one bucket.
 """
 from __future__ import annotations
 
-from typing import Iterable, List
+from typing import Iterable, List, Optional
 
 import torch
 
@@ -45,15 +45,19 @@ class FlatAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def gather_grads(self) -> torch.Tensor:
-        """All gradients as one contiguous bucket (one concatenation kernel)."""
+    def gather_grads(self, first: int = 0, last: Optional[int] = None) -> torch.Tensor:
+        """Gradients of parameters [first, last) concatenated into their part of the flat bucket (one
+        concatenation kernel); by default all of them.  Returns that part (a view of ``flat_grad``)."""
+        last = len(self.params) if last is None else last
         gs = []
-        for p in self.params:
+        for p in self.params[first:last]:
             if p.grad is None:
                 raise RuntimeError("a parameter has no gradient; call backward() first")
             gs.append(p.grad.reshape(-1))
-        torch.cat(gs, out=self.flat_grad)
-        return self.flat_grad
+        lo, hi = sum(self.sizes[:first]), sum(self.sizes[:last])
+        part = self.flat_grad[lo:hi]
+        torch.cat(gs, out=part)
+        return part
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0, grads_gathered: bool = False) -> None:

@@ -96,6 +96,21 @@ def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
     return t
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_reduce_async_(t: torch.Tensor):
+    """Start a summing all-reduce of ``t`` in place and return a handle whose ``wait()`` orders the current
+    stream after it.  Under nccl (RCCL) the collective runs on the communicator's own stream, behind the
+    work already queued on the current stream, so kernels launched next overlap with it."""
+    if _host_staged(t):
+        all_reduce_(t)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def allreduce_gradients_(flat_grad: torch.Tensor, world: int) -> float:
     """Summing all-reduce of the gradient bucket in place; returns the factor the optimizer must
     apply (1/world) so that the update equals that of the global batch (equal shard sizes)."""

@@ -4,9 +4,16 @@ A 1024-ray step is about sixty short kernel launches; issued one by one from Pyt
 the bottleneck.  ``TrainStep`` runs the same call sequence eagerly or captures it once into two HIP
 graphs (forward + backward + gradient bucket; optimizer) and replays them, with the inputs in
 static buffers and the optimizer's hyper-parameters in device memory so that the learning rate can
-change between replays.  Between the two graphs sits the only collective of data-parallel
-training, one summing all-reduce of the flat gradient bucket; a single process has no collective and
-captures the whole step as one graph (a graph boundary idles the GPU for about 9 us).
+change between replays.  A single process captures the whole step as one graph (a graph boundary
+idles the GPU for about 9 us).  Data-parallel training needs the summing all-reduce of the flat gradient
+bucket, which cannot sit inside a graph, and splits the step where the collectives go: the backward
+pass of the fine network comes first and does not depend on the coarse one (the fine sample positions
+are not differentiated, train_nerf.py:318), so its half of the bucket is reduced while the coarse
+network's backward pass runs:
+
+    graph 1: forward (coarse, fine), losses, fine backward      -> all-reduce(fine half), asynchronous
+    graph 2: coarse backward                                    -> all-reduce(coarse half)
+    graph 3: Adam on the whole bucket (scaled by 1/world), weight re-pack
 
 The static input buffers are ``TrainStep.rays_o / rays_d / target``: a producer that writes a batch
 straight into them (``BlenderDataset.sample_rays(out=...)``) and passes those same tensors to the
@@ -21,7 +28,7 @@ import torch
 from . import ops
 from .models.nerf import render_hierarchical
 from .optim import FlatAdam
-from .parallel import allreduce_gradients_
+from .parallel import all_reduce_async_, allreduce_gradients_
 
 
 class TrainStep:
@@ -40,11 +47,19 @@ class TrainStep:
         self.losses = torch.zeros((3,), device=dev)           # total, coarse, fine: written by the loss kernel
         self.loss, self.loss_coarse, self.loss_fine = self.losses[0], self.losses[1], self.losses[2]
         self._g_fb: Optional[torch.cuda.CUDAGraph] = None
+        self._g_coarse: Optional[torch.cuda.CUDAGraph] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
+        # parameters of the fine network as a range [first, last) of the optimizer's list, if they form one
+        fine_ids = {id(p) for p in model_fine.parameters()}
+        idx = [i for i, p in enumerate(optimizer.params) if id(p) in fine_ids]
+        n_par = len(optimizer.params)
+        self._fine = (idx[0], idx[-1] + 1) if 0 < len(idx) < n_par and idx == list(range(idx[0], idx[-1] + 1)) else None
+        if self._fine is not None and not (self._fine[0] == 0 or self._fine[1] == n_par):
+            self._fine = None          # (the coarse parameters must be one range too)
         self.opt.device_state()[4] = 1.0 / world_size        # gradients are summed over ranks, then averaged
 
     # the step body: losses of train_nerf.py:299, :330-331; gradients into the optimizer's flat bucket
-    def _forward_backward(self):
+    def _forward(self):
         # the three uniform draws of a step (train_nerf.py:296, :317, :327) come from one generator call
         n, nc, nf = self.rays_o.shape[0], self.nc, self.nf
         r = torch.rand((n * (2 * nc + 2 * nf),), dtype=torch.float32, device=self.rays_o.device)
@@ -57,8 +72,26 @@ class TrainStep:
         # hands back d loss / d rgb of both maps, which seed the backward pass directly
         _, d_coarse, d_fine = ops.mse_pair_grads(coarse["rgb_map"], fine["rgb_map"], self.target, out=self.losses)
         self.opt.zero_grad(set_to_none=True)
-        torch.autograd.backward([coarse["rgb_map"], fine["rgb_map"]], [d_coarse, d_fine])
+        return coarse["rgb_map"], fine["rgb_map"], d_coarse, d_fine
+
+    def _forward_backward(self):
+        rgb_c, rgb_f, d_c, d_f = self._forward()
+        torch.autograd.backward([rgb_c, rgb_f], [d_c, d_f])
         self.opt.gather_grads()
+
+    # the same, split where the data-parallel collectives go
+    def _forward_backward_fine(self):
+        rgb_c, rgb_f, d_c, d_f = self._forward()
+        torch.autograd.backward([rgb_f], [d_f])
+        self._coarse_root = (rgb_c, d_c)
+        return self.opt.gather_grads(*self._fine)
+
+    def _backward_coarse(self):
+        rgb_c, d_c = self._coarse_root
+        self._coarse_root = None
+        torch.autograd.backward([rgb_c], [d_c])
+        first, last = self._fine
+        return self.opt.gather_grads(0, first) if first > 0 else self.opt.gather_grads(last, None)
 
     def _optimizer(self):
         self.opt.step_dev(grads_gathered=True)
@@ -72,14 +105,24 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb):
-            self._forward_backward()
-            if self.world == 1:
+        if self.world == 1:
+            with torch.cuda.graph(self._g_fb):
+                self._forward_backward()
                 self._optimizer()
-        if self.world > 1:
-            self._g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_opt):
-                self._optimizer()
+            return
+        pool = torch.cuda.graph_pool_handle()      # graph 2 reads what graph 1 saved: one memory pool
+        if self._fine is not None:
+            with torch.cuda.graph(self._g_fb, pool=pool):
+                self._part_fine = self._forward_backward_fine()
+            self._g_coarse = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_coarse, pool=pool):
+                self._part_coarse = self._backward_coarse()
+        else:
+            with torch.cuda.graph(self._g_fb, pool=pool):
+                self._forward_backward()
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt, pool=pool):
+            self._optimizer()
         # capture only records: nothing ran, so neither the weights nor the step counter moved
 
     def prepare(self) -> None:
@@ -101,7 +144,14 @@ class TrainStep:
             if self._g_fb is None:
                 self._capture()
             self._g_fb.replay()
-            if self._g_opt is not None:
+            if self._g_coarse is not None:
+                fine_reduced = all_reduce_async_(self._part_fine)       # overlaps with the coarse backward
+                self._g_coarse.replay()
+                coarse_reduced = all_reduce_async_(self._part_coarse)
+                fine_reduced.wait()
+                coarse_reduced.wait()
+                self._g_opt.replay()
+            elif self._g_opt is not None:
                 allreduce_gradients_(self.opt.flat_grad, self.world)
                 self._g_opt.replay()
         else:
