@@ -164,7 +164,14 @@ def whole_frame_kernels(device):
             raw = torch.randn(n, S, 4, device=device)
             z = 2.0 + torch.cumsum(torch.rand(n, S, device=device), dim=-1) * (4.0 / S)     # increasing depths
             out["composite_fwd_S%d" % S] = rate(lambda: ops.composite(raw, z, False), n * (28 * S + 24))
-            del raw, z
+            # the backward with the cotangents a training step has (d rgb_map; d weights is absent because the
+            # fine sample positions are not differentiated): raw 16S + z 4S + g_rgb 12 in, d_raw 16S out
+            g_rgb, d_raw = torch.randn(n, 3, device=device), torch.empty_like(raw)
+            st = torch.cuda.current_stream().cuda_stream
+            out["composite_bwd_S%d" % S] = rate(lambda: ops.check(ops.lib.nerf_composite_bwd(
+                n, S, raw.data_ptr(), z.data_ptr(), 0, g_rgb.data_ptr(), None, None, None, None, None,
+                d_raw.data_ptr(), st), "nerf_composite_bwd"), n * (36 * S + 12))
+            del raw, z, g_rgb, d_raw
         c2w = torch.eye(4, device=device)[:3].contiguous()
         out["get_rays_800x800"] = rate(lambda: ops.get_rays(800, 800, 1111.0, c2w), n * 24, iters=20)
         out["get_rays_3200x3200"] = rate(lambda: ops.get_rays(3200, 3200, 4444.0, c2w), 16 * n * 24)
