@@ -6,7 +6,8 @@
 // (rounded to fp32 per knot, as the reference's CPU cumsum does) and parked in LDS together
 // with the bin edges; every lane then inverts the CDF for its own uniforms with a binary
 // search over the LDS copy.  The sort is a bitonic network held in registers, E elements per
-// lane, with cross-lane exchanges on wave shuffles.
+// lane, with cross-lane exchanges on wave shuffles; the fused glue kernel replaces it by a merge
+// (one more binary search per element) when its two lists are already ascending.
 // Compiled with -ffp-contract=off (the interpolation is unfused fp32 in the reference).
 #include <math.h>
 #include "common.hpp"
@@ -139,16 +140,34 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(int64_t n_rows, int n_a,
     store_sorted<E>(v, out + row * n, n, lane);
 }
 
-// coarse->fine glue: sample_pdf on (midpoints, w[1:-1]+1e-5) then sort(cat(z_coarse, z_fine))
+// number of elements of the ascending list a[0..n) that are < x (STRICT) or <= x
+template <bool STRICT>
+__device__ __forceinline__ int count_below(const float* __restrict__ a, int n, float x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const bool below = STRICT ? a[mid] < x : a[mid] <= x;
+        if (below) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// coarse->fine glue: sample_pdf on (midpoints, w[1:-1]+1e-5) then sort(cat(z_coarse, z_fine)).
+// With the deterministic uniforms of a render both lists are normally ascending already (checked per ray;
+// rounding in the interpolation can break it by an ulp) and the sort is a merge: every element finds its
+// place with one binary search in the other list (fine before coarse on ties, so places are unique).
+// Otherwise the bitonic network sorts.  LDS per wave: cdf | bin edges | fine then coarse samples | merged row.
 template <int E>
 __global__ __launch_bounds__(256) void sample_merge_kernel(int64_t n_rays, int Sc, const float* __restrict__ zc,
                                                            const float* __restrict__ wc, int n_fine,
                                                            const float* __restrict__ u, float* __restrict__ zout,
-                                                           float* __restrict__ zfine, int lds_stride) {
+                                                           float* __restrict__ zfine, int lds_stride, int n_pad) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* cdf = smem + (size_t)wv * 2 * lds_stride;
+    float* cdf = smem + (size_t)wv * 2 * (lds_stride + n_pad);
     float* lb = cdf + lds_stride;
+    float* lists = lb + lds_stride;
+    float* merged = lists + n_pad;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
     if (ray >= n_rays) return;
     const float* z = zc + ray * Sc;
@@ -173,8 +192,34 @@ __global__ __launch_bounds__(256) void sample_merge_kernel(int64_t n_rays, int S
             x = z[i - n_fine];
         }
         v[r] = x;
+        if (u == nullptr && i < n) lists[i] = x;
     }
-    bitonic_sort<E>(v, lane);
+    // given uniforms are taken to be unordered (the stratified draws of training): straight to the sort
+    bool ascending = u == nullptr;
+    if (ascending) {
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int i = r * 64 + lane;
+            if (i < n && i != n_fine - 1 && i != n - 1) ascending = ascending && (v[r] <= lists[i + 1]);   // false on NaN
+        }
+        ascending = __all(ascending);
+    }
+    if (ascending) {
+        const float* fine = lists;
+        const float* coarse = lists + n_fine;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int i = r * 64 + lane;
+            if (i < n_fine) merged[i + count_below<true>(coarse, Sc, v[r])] = v[r];
+            else if (i < n) merged[(i - n_fine) + count_below<false>(fine, n_fine, v[r])] = v[r];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < E; ++r) v[r] = lane * E + r < n ? merged[lane * E + r] : INFINITY;
+    } else {
+        bitonic_sort<E>(v, lane);
+    }
     store_sorted<E>(v, zout + ray * n, n, lane);
 }
 
@@ -228,15 +273,15 @@ extern "C" int nerf_sample_merge(int64_t n_rays, int Sc, const float* z_coarse, 
     NERF_REQUIRE(z_coarse && w_coarse && z_out, NERF_E_NULL);
     NERF_REQUIRE(n_rays >= 0 && Sc >= 3 && Sc <= 1024 && n_fine >= 1 && Sc + n_fine <= 1024, NERF_E_SHAPE);
     if (n_rays == 0) return NERF_OK;
-    const int lds_stride = (Sc + 3) & ~3;
-    const size_t lds = (size_t)4 * 2 * lds_stride * sizeof(float);
+    const int lds_stride = (Sc + 3) & ~3, n_pad = (Sc + n_fine + 3) & ~3;
+    const size_t lds = (size_t)4 * 2 * (lds_stride + n_pad) * sizeof(float);        // at most 64 KiB
     const int64_t blocks = (n_rays + 3) / 4;
     NERF_REQUIRE(blocks <= 0x7fffffff, NERF_E_SHAPE);
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define NERF_SM(E)                                                                                        \
     hipLaunchKernelGGL(nerf::sample_merge_kernel<E>, grid, block, lds, st, n_rays, Sc, z_coarse, w_coarse, \
-                       n_fine, u, z_out, z_fine_out, lds_stride)
+                       n_fine, u, z_out, z_fine_out, lds_stride, n_pad)
     switch (nerf::elems_per_lane(Sc + n_fine)) {
         case 1: NERF_SM(1); break;
         case 2: NERF_SM(2); break;

@@ -96,6 +96,19 @@ def test_sample_merge_chunk_properties():
         assert (z_fine >= mids[:, :1] - 1e-6).all().item() and (z_fine <= mids[:, -1:] + 1e-6).all().item()
         part = ops.sample_merge(zc[999:5000], w[999:5000], Nf, det, u=None if u is None else u[999:5000])
         assert torch.equal(part, z_all[999:5000])
+    # deterministic mode merges two ascending lists instead of sorting; inputs that are not ascending, and
+    # inputs full of ties between and inside the lists, must still come out as torch.sort orders them
+    def reference(zc_, w_):
+        mids_ = 0.5 * (zc_[:, 1:] + zc_[:, :-1])
+        zf = ops.sample_pdf(mids_, w_[:, 1:-1] + 1e-5, Nf, det=True)
+        return torch.sort(torch.cat([zc_, zf], dim=-1), dim=-1).values
+    zq = torch.round(zc[:4096] * 4.0) / 4.0                     # 17 distinct depths per ray: ties everywhere
+    assert torch.equal(ops.sample_merge(zq, w[:4096], Nf, True), reference(zq, w[:4096]))
+    zr = zc[:4096].flip(-1).contiguous()                        # descending coarse depths
+    assert torch.equal(ops.sample_merge(zr, w[:4096], Nf, True), reference(zr, w[:4096]))
+    zs = zc[:4096].clone()
+    zs[:, 40] = zs[:, 10]                                       # one element out of order
+    assert torch.equal(ops.sample_merge(zs, w[:4096], Nf, True), reference(zs, w[:4096]))
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
