@@ -104,24 +104,27 @@ class TrainStep:
                 self._forward_backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # other threads of the process (the collective library's watchdog polls events) must not be able to
+        # invalidate the capture: only this thread's calls are checked
+        MODE = "thread_local"
         self._g_fb = torch.cuda.CUDAGraph()
         if self.world == 1:
-            with torch.cuda.graph(self._g_fb):
+            with torch.cuda.graph(self._g_fb, capture_error_mode=MODE):
                 self._forward_backward()
                 self._optimizer()
             return
         pool = torch.cuda.graph_pool_handle()      # graph 2 reads what graph 1 saved: one memory pool
         if self._fine is not None:
-            with torch.cuda.graph(self._g_fb, pool=pool):
+            with torch.cuda.graph(self._g_fb, pool=pool, capture_error_mode=MODE):
                 self._part_fine = self._forward_backward_fine()
             self._g_coarse = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_coarse, pool=pool):
+            with torch.cuda.graph(self._g_coarse, pool=pool, capture_error_mode=MODE):
                 self._part_coarse = self._backward_coarse()
         else:
-            with torch.cuda.graph(self._g_fb, pool=pool):
+            with torch.cuda.graph(self._g_fb, pool=pool, capture_error_mode=MODE):
                 self._forward_backward()
         self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, pool=pool):
+        with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode=MODE):
             self._optimizer()
         # capture only records: nothing ran, so neither the weights nor the step counter moved
 
