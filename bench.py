@@ -278,6 +278,25 @@ def main():
     step_fn.rays_o.copy_(rays_o); step_fn.rays_d.copy_(rays_d); step_fn.target.copy_(target)
     rays_o, rays_d, target = step_fn.rays_o, step_fn.rays_d, step_fn.target
 
+    # Capture the graphs before the first collective of a step.  If capture fails on any rank, every rank
+    # falls back to issuing the launches from Python (slower, still the same work) and the line says so.
+    graph_error = None
+    if not args.no_graph:
+        try:
+            step_fn.prepare()
+        except Exception as e:      # noqa: BLE001
+            graph_error = "%s: %s" % (type(e).__name__, str(e)[:200])
+        failed = torch.tensor([0.0 if graph_error is None else 1.0], device=device)
+        if world > 1:
+            from nerf_amd.parallel import all_reduce_
+            all_reduce_(failed, op=dist.ReduceOp.MAX)
+        if failed.item() > 0:
+            graph_error = graph_error or "graph capture failed on another rank"
+            print("bench.py: " + graph_error + "; continuing without graphs", file=sys.stderr, flush=True)
+            step_fn = TrainStep(mc, mf, pe, pv, opt, n, near=2.0, far=6.0, N_samples_coarse=64, N_samples_fine=128,
+                                world_size=world, use_graph=False)
+    stage("graphs captured" if graph_error is None else "no graphs")
+
     def lr_at(i):      # scripts/train_nerf.py:288: lr0 * decay^(step / decay_steps)
         return 5e-4 * (0.1 ** (i / 250000.0))
 
@@ -366,7 +385,7 @@ def main():
                                    "NeRF, fwd+bwd+Adam (benchmark configuration: single training step, batch 1024 rays)" % n,
                        "rays_per_gpu": n, "global_rays": n * world, "samples_per_ray": "64+192 evaluations",
                        "parallelism": "dp%d" % world if world > 1 else "single"},
-            "launch_mode": "eager" if args.no_graph else ("hipgraph replay (one graph per step)" if world == 1 else
+            "launch_mode": "eager" if args.no_graph else ("eager (%s)" % graph_error) if graph_error else ("hipgraph replay (one graph per step)" if world == 1 else
                                                          "hipgraph replay (3 graphs per step: the all-reduce of the fine network's gradients overlaps the "
                                                          "coarse backward, the coarse half follows, then Adam)"),
             "roofline": roofline, "kernels": kernels,
