@@ -134,6 +134,20 @@ def render_section(mc, mf, pe, pv, device, args):
                 e["frac_of_hbm_peak"] = round(e["GB/s"] / HBM_PEAK_GBS, 4)
             sec["kernels"][name] = e
         out.append(sec)
+    # frames of the 120-pose camera path with the white background and inverse-depth sampling
+    # (render_nerf.py:145-149 with --white_bkgd --lindisp): render, clip, uint8 on the device, copy to the host
+    from nerf_amd.render import render_path
+    from nerf_amd.utils.synthetic import camera_path
+    poses = camera_path(120).to(device)[::30]
+    render_path(mc, mf, pe, pv, H, W, focal, poses[:1], chunk=args.render_chunk[0], lindisp=True, white_bkgd=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = render_path(mc, mf, pe, pv, H, W, focal, poses, chunk=args.render_chunk[0], lindisp=True, white_bkgd=True)
+    dt = (time.perf_counter() - t0) / len(poses)
+    out.append({"workload": "camera path: %d of the 120 poses, 800x800, 64+128 samples, lindisp, white background, chunk %d, "
+                            "uint8 frames on the host" % (len(poses), args.render_chunk[0]),
+                "s_per_frame": round(dt, 4), "frames_per_s": round(1.0 / dt, 2), "rays_per_s": round(H * W / dt, 1),
+                "frames": len(frames), "kernels": {}})
     return out
 
 
@@ -232,9 +246,20 @@ def cpu_baseline(n_rays, steps):
     for _ in range(steps):
         one()
     dt = (time.perf_counter() - t0) / steps
+    # the render path of the same oracle (no_grad, deterministic, both passes) on the same rays
+    with torch.no_grad():
+        pcd, pfd = {k: v.detach() for k, v in pc.items()}, {k: v.detach() for k, v in pf.items()}
+        O.render_hierarchical(pcd, pfd, ro, rd, 2.0, 6.0, 64, 128, det=True)
+        t1 = time.perf_counter()
+        reps = max(1, steps // 2)
+        for _ in range(reps):
+            O.render_hierarchical(pcd, pfd, ro, rd, 2.0, 6.0, 64, 128, det=True)
+        dt_render = (time.perf_counter() - t1) / reps
     return {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{steps} training steps of {n_rays} rays (64+128 samples, fwd+bwd+Adam), fp32 torch CPU, "
-                      f"{threads} threads, after 1 warm-up step"}
+                      f"{threads} threads, after 1 warm-up step",
+            "render_rays_per_s": n_rays / dt_render,
+            "render_sample": f"{reps} no_grad deterministic renders of the same {n_rays} rays (64+128 samples)"}
 
 
 def stage(msg):
