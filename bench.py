@@ -346,9 +346,19 @@ def main():
         step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + args.steps + 1 + s))
     sync()
     times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+    allreduce_us = None
     if world > 1:
         from nerf_amd.parallel import all_reduce_
         dt = float(all_reduce_(torch.tensor([dt], dtype=torch.float64, device=device), op=dist.ReduceOp.MAX).item())
+        # the collective on its own: the whole gradient bucket, back to back, after the timed region
+        scratch_bucket = torch.zeros_like(opt.flat_grad)
+        all_reduce_(scratch_bucket)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            all_reduce_(scratch_bucket)
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - t1) / 10 * 1e6
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss")
 
@@ -415,6 +425,11 @@ def main():
                                                          "coarse backward, the coarse half follows, then Adam)"),
             "roofline": roofline, "kernels": kernels,
         }
+        if allreduce_us is not None:
+            out["allreduce"] = {"bytes": int(opt.flat_grad.numel()) * 4, "avg_us": round(allreduce_us, 1),
+                                "note": "summing all-reduce of the whole fp32 gradient bucket of both networks, 10 back to back "
+                                        "on rank 0's clock; in a step it is issued as two halves, the first hidden behind the "
+                                        "coarse network's backward pass"}
         if world == 1 and not args.no_render:
             out["render"] = render_section(mc, mf, pe, pv, device, args)
             out["whole_frame_kernels"] = whole_frame_kernels(device)
