@@ -158,3 +158,25 @@ def test_trainer_checkpoint_resume(tmp_path):
     frame = render_image(mc, mf, pe, pv, ck["H"], ck["W"], ck["focal"], ds.poses[0], near=2.0, far=6.0,
                          white_bkgd=True)
     assert frame.shape == (16, 16, 3) and torch.isfinite(frame).all()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_training_learns_a_scene_and_generalises(tmp_path, precision):
+    """Loader -> ray sampler -> graph-replayed training steps -> renderer on a scene with real 3-D structure
+    (an analytically rendered shaded sphere, 12 views of 64x64): after 1500 steps of 1024 rays the two
+    held-out views, never seen in training, are reproduced at more than 22 dB (7.5 dB at initialisation;
+    27-28 dB measured after 2000 steps)."""
+    from util import make_sphere_scene
+    from nerf_amd.datasets import BlenderDataset
+    from nerf_amd.render import evaluate
+    from nerf_amd.trainer import TrainConfig, Trainer
+    make_sphere_scene(str(tmp_path))
+    train, val = BlenderDataset(str(tmp_path), "train"), BlenderDataset(str(tmp_path), "val")
+    tr = Trainer(train, TrainConfig(basedir=str(tmp_path), expname="sphere", batch_size=1024, precision=precision,
+                                    log_freq=500, save_freq=10 ** 6), log=None)
+    before = evaluate(tr.model_coarse, tr.model_fine, tr.pe, tr.pv, val)["psnr"]
+    tr.fit(num_epochs=10 ** 6, max_steps=1500)
+    after = evaluate(tr.model_coarse, tr.model_fine, tr.pe, tr.pv, val)["psnr"]
+    assert all(v < 12.0 for v in before.values()), before
+    assert all(v > 22.0 for v in after.values()), after
+    assert tr.history and tr.history[-1]["loss_fine"] < 2e-3
