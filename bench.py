@@ -12,7 +12,7 @@ all-reduce of the flat 4.77 MB bucket before the optimizer step.  Inputs are syn
 Blender-style camera, random-init weights, uniform targets) and resident in HBM.
 
 Rank 0 prints one JSON line.  `value` = rays processed by all ranks / wall time (max over ranks).
-The timed steps replay the step from HIP graphs (a 1024-ray step is ~60 short launches; issued from
+The timed steps replay the step from HIP graphs (a 1024-ray step is 28 short launches; issued from
 Python the host would be the bottleneck).  `roofline` describes the kernel with the largest share of
 GPU time in the step; its duration comes from HIP events recorded on the launch stream around every
 launch while the same step is issued eagerly right after the timed region.  `cpu_baseline` times the CPU oracle

@@ -7,7 +7,7 @@
 //     stream.  ReLU masks are the sign bits the forward kept, fetched by LDS-DMA.  Every layer's dZ
 //     (except dF, see "factored gradients" in mlp_common.hpp) is written out (16 bit) in
 //     [32 samples][16 positions] units for the weight-gradient pass.
-//  2. mlp_wgrad_kernel -- dW = sum over samples dZ x In^T: 13 GEMMs whose contraction index is the
+//  2. mlp_wgrad_kernel -- dW = sum over samples dZ x In^T: 10 GEMMs whose contraction index is the
 //     sample.  Units are DMA-copied into LDS as they are and read back with ds_read_b64_tr_b16,
 //     which delivers the [feature][8 samples] fragments the MFMA wants.  The sample axis is
 //     split across workgroups; each writes an fp32 partial block.  HBM-bound: every saved unit and

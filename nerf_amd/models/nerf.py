@@ -66,15 +66,15 @@ def _consecutive_view(ps) -> Optional[torch.Tensor]:
 class NeRF(nn.Module):
     """The NeRF MLP with the reference's parameters (nerf.py:126-153) and forward (nerf.py:173-209).
 
-    The HIP kernels implement the architecture the reference's scripts instantiate
-    (D=8, W=256, input_ch_pts=63, input_ch_views=27, skips=[4], use_viewdirs=True); any other
-    configuration can be constructed (for state_dict compatibility) but raises
-    ``NotImplementedError`` when run.
+    The fused HIP kernels implement the architecture the reference's scripts instantiate
+    (D=8, W=256, input_ch_pts=63, input_ch_views=27, skips=[4], use_viewdirs=True).
 
     ``precision`` selects the MFMA operand type ('bf16' or 'fp16'); accumulation is fp32.
     ``precision='fp32'`` is the validation mode: the layers run one by one as fp32 library GEMMs
-    (rocBLAS through ``torch.nn.functional.linear``) under plain autograd, for every architecture
-    the constructor accepts; the encodings and compositing around it are still the HIP kernels.
+    (rocBLAS through ``torch.nn.functional.linear``) under plain autograd; the encodings and
+    compositing around it are still the HIP kernels.  An architecture outside the fused kernels
+    (other D / W / skips / encodings) runs in that fp32 mode whatever ``precision`` says
+    (``effective_precision()`` reports it).
     """
 
     def __init__(self, D: int = 8, W: int = 256, input_ch_pts: int = 63, input_ch_views: int = 27,
@@ -106,7 +106,11 @@ class NeRF(nn.Module):
         """True when calls go to the fused 16-bit MFMA kernels."""
         if self.precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {_PRECISIONS}, got {self.precision!r}")
-        return self.precision in _FUSED_PRECISIONS
+        return self.precision in _FUSED_PRECISIONS and self.kernel_supported()
+
+    def effective_precision(self) -> str:
+        """The precision calls actually run in: ``precision``, or 'fp32' for an architecture outside the fused kernels."""
+        return self.precision if self.fused() else "fp32"
 
     def _require_supported(self):
         if not self.kernel_supported():
@@ -120,6 +124,12 @@ class NeRF(nn.Module):
     def ordered_params(self) -> List[torch.Tensor]:
         """Parameters in state_dict order (the order of the flat buffer the kernels index)."""
         return list(self.parameters())
+
+    def invalidate_packed(self) -> None:
+        """Forget the cached packed weights.  Needed after the weights were rewritten on the device behind
+        PyTorch's back (a HIP-graph replay of an optimizer step, a collective on the optimizer's flat
+        bucket): such writes do not advance the version counters the cache is keyed on."""
+        self._pack_key = None
 
     def packed_weights(self) -> torch.Tensor:
         """MFMA fragment streams of the current weights.  While gradients are being recorded the
@@ -153,7 +163,6 @@ class NeRF(nn.Module):
             raise ValueError("View directions (x_views_encoded) must be provided when use_viewdirs is True.")
         if not self.fused():
             return self._forward_fp32(x_pts_encoded, x_views_encoded)
-        self._require_supported()
         if x_pts_encoded.shape[-1] != 63 or x_views_encoded.shape[-1] != 27:
             raise ValueError("expected encoded inputs of width 63 and 27")
         if x_pts_encoded.shape[:-1] != x_views_encoded.shape[:-1]:
@@ -212,7 +221,7 @@ def render_rays(nerf_model, embed_fn_pts, embed_fn_views, rays_o: torch.Tensor, 
     else:
         z_vals = ops.place_samples(n_rays, near, far, N_samples, lindisp, dev, z_vals_override, t_rand)
 
-    fused = (isinstance(nerf_model, NeRF) and nerf_model.fused() and nerf_model.kernel_supported() and use_viewdirs
+    fused = (isinstance(nerf_model, NeRF) and nerf_model.fused() and use_viewdirs
              and isinstance(embed_fn_pts, PositionalEncoder) and embed_fn_pts.is_standard(10)
              and isinstance(embed_fn_views, PositionalEncoder) and embed_fn_views.is_standard(4))
     if fused:

@@ -257,15 +257,16 @@ def mse_pair(rgb_coarse: torch.Tensor, rgb_fine: torch.Tensor, target: torch.Ten
 def mse_pair_grads(rgb_coarse: torch.Tensor, rgb_fine: torch.Tensor, target: torch.Tensor,
                    out: Optional[torch.Tensor] = None):
     """The same launch outside autograd: ((total, loss_coarse, loss_fine), d total/d rgb_coarse,
-    d total/d rgb_fine).  ``torch.autograd.backward([rgb_coarse, rgb_fine], [d_coarse, d_fine])`` is then
+    d total/d rgb_fine).  ``rgb_fine=None`` is the coarse-only loss (total = loss_coarse, loss_fine = 0).  ``torch.autograd.backward([rgb_coarse, rgb_fine], [d_coarse, d_fine])`` is then
     ``total.backward()`` without the unit root gradient and the two products with it."""
-    a, b, target = _gpu_f32(rgb_coarse, "rgb_coarse"), _gpu_f32(rgb_fine, "rgb_fine"), _gpu_f32(target, "target_rgb")
-    if a.shape != target.shape or b.shape != target.shape:
-        raise ValueError(f"rgb maps and target must agree in shape: {tuple(a.shape)}, {tuple(b.shape)}, "
-                         f"{tuple(target.shape)}")
+    a, target = _gpu_f32(rgb_coarse, "rgb_coarse"), _gpu_f32(target, "target_rgb")
+    b = None if rgb_fine is None else _gpu_f32(rgb_fine, "rgb_fine")     # coarse-only run: one loss
+    if a.shape != target.shape or (b is not None and b.shape != target.shape):
+        raise ValueError(f"rgb maps and target must agree in shape: {tuple(a.shape)}, "
+                         f"{None if b is None else tuple(b.shape)}, {tuple(target.shape)}")
     dev = a.device
     losses = out if out is not None else torch.empty((3,), dtype=torch.float32, device=dev)
-    da, db = torch.empty_like(a), torch.empty_like(b)
+    da, db = torch.empty_like(a), (None if b is None else torch.empty_like(b))
     with torch.cuda.device(dev):
         check(lib.nerf_mse_pair(a.numel(), _p(a), _p(b), _p(target), _p(losses), _p(da), _p(db), _stream(dev)),
               "nerf_mse_pair")

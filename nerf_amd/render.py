@@ -23,6 +23,9 @@ def render_image(model_coarse, model_fine, embed_fn_pts, embed_fn_views, H: int,
     [nrows, W, 3] block is returned.  ``chunk`` is the number of rays per launch group (the
     reference's eval_batch_size, render_nerf.py:55; the kernels prefer larger chunks than 4096).
     ``model_fine=None`` renders the coarse pass only (render_nerf.py:282-285)."""
+    # a checkpoint trained without view directions has no view encoder (render_nerf.py:278, :300 pass
+    # use_viewdirs=use_viewdirs_model)
+    use_viewdirs = embed_fn_views is not None and getattr(model_coarse, "use_viewdirs", True)
     row0, nrows = shard_rows(H, rank, world_size)
     rays_o, rays_d = get_rays(H, W, focal, c2w, row0=row0, nrows=nrows)
     rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
@@ -31,11 +34,11 @@ def render_image(model_coarse, model_fine, embed_fn_pts, embed_fn_views, H: int,
         ro, rd = rays_o[s:s + chunk], rays_d[s:s + chunk]
         if model_fine is None:
             res = render_rays(model_coarse, embed_fn_pts, embed_fn_views, ro, rd, near, far, N_samples_coarse,
-                              rand=False, lindisp=lindisp, white_bkgd=white_bkgd)
+                              rand=False, lindisp=lindisp, use_viewdirs=use_viewdirs, white_bkgd=white_bkgd)
         else:
             _, res = render_hierarchical(model_coarse, model_fine, embed_fn_pts, embed_fn_views, ro, rd, near, far,
                                          N_samples_coarse, N_samples_fine, rand=False, det=True, lindisp=lindisp,
-                                         white_bkgd=white_bkgd)
+                                         use_viewdirs=use_viewdirs, white_bkgd=white_bkgd)
         out[s:s + chunk] = res["rgb_map"]
     block = out.reshape(nrows, W, 3)
     return gather_rows(block, H, rank, world_size) if gather else block

@@ -1,11 +1,11 @@
 """The training step of scripts/train_nerf.py:288-336 as one callable, optionally replayed from a HIP graph.
 
-A 1024-ray step is about sixty short kernel launches; issued one by one from Python the host is
-the bottleneck.  ``TrainStep`` runs the same call sequence eagerly or captures it once into two HIP
-graphs (forward + backward + gradient bucket; optimizer) and replays them, with the inputs in
-static buffers and the optimizer's hyper-parameters in device memory so that the learning rate can
-change between replays.  A single process captures the whole step as one graph (a graph boundary
-idles the GPU for about 9 us).  Data-parallel training needs the summing all-reduce of the flat gradient
+A 1024-ray step is 28 short kernel launches; issued one by one from Python the host is
+the bottleneck.  ``TrainStep`` runs the same call sequence eagerly or captures it once into HIP
+graphs and replays them, with the inputs in static buffers and the optimizer's hyper-parameters in
+device memory so that the learning rate can change between replays.  A single process captures the
+whole step (forward, backward, gradient bucket, optimizer, weight re-pack) as one graph (a graph
+boundary idles the GPU for about 9 us).  Data-parallel training needs the summing all-reduce of the flat gradient
 bucket, which cannot sit inside a graph, and splits the step where the collectives go: the backward
 pass of the fine network comes first and does not depend on the coarse one (the fine sample positions
 are not differentiated, train_nerf.py:318), so its half of the bucket is reduced while the coarse
@@ -26,7 +26,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .models.nerf import render_hierarchical
+from .models.nerf import render_hierarchical, render_rays
 from .optim import FlatAdam
 from .parallel import all_reduce_async_, allreduce_gradients_
 
@@ -34,13 +34,24 @@ from .parallel import all_reduce_async_, allreduce_gradients_
 class TrainStep:
     def __init__(self, model_coarse, model_fine, embed_fn_pts, embed_fn_views, optimizer: FlatAdam, n_rays: int,
                  near: float = 2.0, far: float = 6.0, N_samples_coarse: int = 64, N_samples_fine: int = 128,
-                 lindisp: bool = False, white_bkgd: bool = False, world_size: int = 1, use_graph: bool = True):
+                 lindisp: bool = False, white_bkgd: bool = False, world_size: int = 1, use_graph: bool = True,
+                 external_uniforms: bool = False):
+        """``model_fine=None`` is the coarse-only run of train_nerf.py:303 (no ``--use_hierarchical``);
+        ``embed_fn_views=None`` (or a model built with ``use_viewdirs=False``) the run without
+        ``--use_viewdirs`` (train_nerf.py:79, :181-184).  With ``external_uniforms`` the step reads its
+        uniform draws from the static buffer ``self.uniforms`` instead of generating them (parity tests
+        inject the reference's draws there): [n, Nc] jitter of the coarse pass, then [n, Nf] inverse-CDF
+        uniforms and [n, Nc+Nf] jitter of the fine pass, flattened and concatenated."""
         self.mc, self.mf, self.pe, self.pv, self.opt = model_coarse, model_fine, embed_fn_pts, embed_fn_views, optimizer
         self.near, self.far, self.nc, self.nf = near, far, N_samples_coarse, N_samples_fine
         self.lindisp, self.white = lindisp, white_bkgd
         self.world = world_size
         self.use_graph = use_graph
+        self.hier = model_fine is not None
+        self.use_viewdirs = embed_fn_views is not None and bool(getattr(model_coarse, "use_viewdirs", True))
         dev = optimizer.flat.device
+        self.n_uniforms = n_rays * ((2 * N_samples_coarse + 2 * N_samples_fine) if self.hier else N_samples_coarse)
+        self.uniforms = torch.zeros((self.n_uniforms,), device=dev) if external_uniforms else None
         self.rays_o = torch.zeros((n_rays, 3), device=dev)
         self.rays_d = torch.zeros((n_rays, 3), device=dev)
         self.target = torch.zeros((n_rays, 3), device=dev)
@@ -50,7 +61,7 @@ class TrainStep:
         self._g_coarse: Optional[torch.cuda.CUDAGraph] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
         # parameters of the fine network as a range [first, last) of the optimizer's list, if they form one
-        fine_ids = {id(p) for p in model_fine.parameters()}
+        fine_ids = {id(p) for p in model_fine.parameters()} if self.hier else set()
         idx = [i for i, p in enumerate(optimizer.params) if id(p) in fine_ids]
         n_par = len(optimizer.params)
         self._fine = (idx[0], idx[-1] + 1) if 0 < len(idx) < n_par and idx == list(range(idx[0], idx[-1] + 1)) else None
@@ -62,12 +73,22 @@ class TrainStep:
     def _forward(self):
         # the three uniform draws of a step (train_nerf.py:296, :317, :327) come from one generator call
         n, nc, nf = self.rays_o.shape[0], self.nc, self.nf
-        r = torch.rand((n * (2 * nc + 2 * nf),), dtype=torch.float32, device=self.rays_o.device)
+        r = self.uniforms
+        if r is None:
+            r = torch.rand((self.n_uniforms,), dtype=torch.float32, device=self.rays_o.device)
+        if not self.hier:           # train_nerf.py:293-303: total_loss = loss_coarse
+            coarse = render_rays(self.mc, self.pe, self.pv, self.rays_o, self.rays_d, self.near, self.far, nc,
+                                 rand=True, lindisp=self.lindisp, use_viewdirs=self.use_viewdirs,
+                                 white_bkgd=self.white, t_rand=r.view(n, nc))
+            _, d_coarse, _ = ops.mse_pair_grads(coarse["rgb_map"], None, self.target, out=self.losses)
+            self.opt.zero_grad(set_to_none=True)
+            return coarse["rgb_map"], None, d_coarse, None
         t_c, u_f, t_f = (r[:n * nc].view(n, nc), r[n * nc:n * (nc + nf)].view(n, nf),
                          r[n * (nc + nf):].view(n, nc + nf))
         coarse, fine = render_hierarchical(self.mc, self.mf, self.pe, self.pv, self.rays_o, self.rays_d, self.near,
                                            self.far, self.nc, self.nf, rand=True, det=False, lindisp=self.lindisp,
-                                           white_bkgd=self.white, t_rand_coarse=t_c, u_fine=u_f, t_rand_fine=t_f)
+                                           use_viewdirs=self.use_viewdirs, white_bkgd=self.white, t_rand_coarse=t_c,
+                                           u_fine=u_f, t_rand_fine=t_f)
         # loss.backward() of train_nerf.py:334 with the unit root gradient folded away: the loss kernel
         # hands back d loss / d rgb of both maps, which seed the backward pass directly
         _, d_coarse, d_fine = ops.mse_pair_grads(coarse["rgb_map"], fine["rgb_map"], self.target, out=self.losses)
@@ -76,7 +97,10 @@ class TrainStep:
 
     def _forward_backward(self):
         rgb_c, rgb_f, d_c, d_f = self._forward()
-        torch.autograd.backward([rgb_c, rgb_f], [d_c, d_f])
+        if rgb_f is None:
+            torch.autograd.backward([rgb_c], [d_c])
+        else:
+            torch.autograd.backward([rgb_c, rgb_f], [d_c, d_f])
         self.opt.gather_grads()
 
     # the same, split where the data-parallel collectives go
@@ -161,4 +185,9 @@ class TrainStep:
             self._forward_backward()
             allreduce_gradients_(self.opt.flat_grad, self.world)
             self._optimizer()
+        # A graph replay rewrites the weights on the device without touching the parameters' version
+        # counters, which the models' no_grad cache of packed weights is keyed on: drop the caches.
+        self.mc.invalidate_packed()
+        if self.mf is not None:
+            self.mf.invalidate_packed()
         return self.loss

@@ -26,7 +26,8 @@ from .train import TrainStep
 
 @dataclasses.dataclass
 class TrainConfig:
-    """Options of train_nerf.py:49-85 that the loop uses, with the script's defaults."""
+    """Options of train_nerf.py:49-85 that the loop uses, with the script's defaults (``use_hierarchical``
+    and ``use_viewdirs`` are store_true flags there: off unless given)."""
     expname: str = "nerf"
     basedir: str = "./logs/"
     white_bkgd: bool = False
@@ -34,7 +35,7 @@ class TrainConfig:
     far: float = 6.0
     N_samples_coarse: int = 64
     N_samples_fine: int = 128
-    use_hierarchical: bool = True
+    use_hierarchical: bool = False
     lindisp: bool = False
     num_epochs: int = 200
     batch_size: int = 1024               # rays per step and per rank
@@ -46,7 +47,7 @@ class TrainConfig:
     net_width: int = 256
     input_ch_pts_L: int = 10
     input_ch_views_L: int = 4
-    use_viewdirs: bool = True
+    use_viewdirs: bool = False
     log_freq: int = 100
     save_freq: int = 10                  # epochs
     precision: str = "bf16"
@@ -65,23 +66,26 @@ def learning_rate(cfg: TrainConfig, global_step: int) -> float:
 class Trainer:
     def __init__(self, dataset, cfg: TrainConfig, rank: int = 0, world_size: int = 1, device="cuda",
                  use_graph: bool = True, log: Optional[Callable[[str], None]] = print):
-        if not cfg.use_hierarchical or not cfg.use_viewdirs:
-            raise NotImplementedError("the fused training step is the hierarchical, view-dependent configuration "
-                                      "(--use_hierarchical --use_viewdirs)")
         self.cfg, self.data, self.rank, self.world = cfg, dataset, rank, world_size
         self.device = torch.device(device)
         self.log = log if rank == 0 else None
         torch.manual_seed(cfg.seed)                                       # train_nerf.py:149-152
+        # encoders and networks as train_nerf.py:177-200 builds them
         self.pe = PositionalEncoder(3, cfg.input_ch_pts_L).to(self.device)
-        self.pv = PositionalEncoder(3, cfg.input_ch_views_L).to(self.device)
+        self.pv = PositionalEncoder(3, cfg.input_ch_views_L).to(self.device) if cfg.use_viewdirs else None
         kw = dict(D=cfg.net_depth, W=cfg.net_width, input_ch_pts=self.pe.output_dims,
-                  input_ch_views=self.pv.output_dims, skips=[cfg.net_depth // 2], use_viewdirs=True,
-                  precision=cfg.precision)
+                  input_ch_views=self.pv.output_dims if cfg.use_viewdirs else 0, skips=[cfg.net_depth // 2],
+                  use_viewdirs=cfg.use_viewdirs, precision=cfg.precision)
         self.model_coarse = NeRF(**kw).to(self.device)
-        self.model_fine = NeRF(**kw).to(self.device)
-        params = list(self.model_coarse.parameters()) + list(self.model_fine.parameters())   # train_nerf.py:203-206
+        self.model_fine = NeRF(**kw).to(self.device) if cfg.use_hierarchical else None
+        params = list(self.model_coarse.parameters())                     # train_nerf.py:203-206
+        if self.model_fine is not None:
+            params += list(self.model_fine.parameters())
         self.optimizer = FlatAdam(params, lr=cfg.lr)
         broadcast_parameters_(self.optimizer.flat, world_size)
+        # every rank starts from rank 0's weights but draws its own jitter and inverse-CDF uniforms, so that an
+        # N-rank step is one step over N * batch_size rays with independent draws
+        torch.manual_seed(cfg.seed + rank)
         self.step_fn = TrainStep(self.model_coarse, self.model_fine, self.pe, self.pv, self.optimizer, cfg.batch_size,
                                  near=cfg.near, far=cfg.far, N_samples_coarse=cfg.N_samples_coarse,
                                  N_samples_fine=cfg.N_samples_fine, lindisp=cfg.lindisp, white_bkgd=cfg.white_bkgd,
@@ -104,12 +108,15 @@ class Trainer:
         self.global_step += 1
         if self.global_step % self.cfg.log_freq == 0:
             lc, lf = float(self.step_fn.loss_coarse), float(self.step_fn.loss_fine)     # the only host syncs
-            rec = {"global_step": self.global_step, "lr": lr, "loss": lc + lf, "loss_coarse": lc, "loss_fine": lf,
-                   "psnr_coarse": mse_to_psnr(lc), "psnr_fine": mse_to_psnr(lf)}
+            rec = {"global_step": self.global_step, "lr": lr, "loss": lc + lf, "loss_coarse": lc,
+                   "psnr_coarse": mse_to_psnr(lc)}
+            msg = f"GS: {rec['global_step']} LR: {lr:.7f} Loss_T: {rec['loss']:.4f} PSNR_c: {rec['psnr_coarse']:.2f}"
+            if self.model_fine is not None:                                # train_nerf.py:353-355
+                rec.update(loss_fine=lf, psnr_fine=mse_to_psnr(lf))
+                msg += f" Loss_f: {lf:.4f} PSNR_f: {rec['psnr_fine']:.2f}"
             self.history.append(rec)
             if self.log:
-                self.log(f"GS: {rec['global_step']} LR: {lr:.7f} Loss_T: {rec['loss']:.4f} PSNR_c: "
-                         f"{rec['psnr_coarse']:.2f} Loss_f: {lf:.4f} PSNR_f: {rec['psnr_fine']:.2f}")
+                self.log(msg)
         return loss
 
     def fit(self, num_epochs: Optional[int] = None, max_steps: Optional[int] = None) -> None:
@@ -157,9 +164,12 @@ class Trainer:
             path = alt
         ck = ckpt_io.load_checkpoint(path, map_location=self.device)
         for model, key in ((self.model_coarse, "model_coarse_state_dict"), (self.model_fine, "model_fine_state_dict")):
+            if model is None:
+                continue
             if key not in ck:
                 raise ValueError(f"{path} has no '{key}'")
             model.load_state_dict(ck[key])      # copies in place: the parameters stay views of the flat bucket
+            model.invalidate_packed()
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
         self.epoch = int(ck.get("epoch", -1)) + 1
         self.global_step = int(ck.get("global_step", 0))

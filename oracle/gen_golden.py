@@ -284,6 +284,142 @@ for tag, m, po in (("c", mc_t, pco), ("f", mf_t, pfo)):
     f9[f"g_{tag}_l5_w_head"] = m.pts_linears[5].weight.grad[:8, :80].clone()
 save("f9_train_step", **f9)
 
+
+# ---- F8b end-to-end config 1 with a well-conditioned weight set ---------------------------------------
+# With random-init weights 1-2 % of rays have |raw_sigma_last| below the 16-bit operand-rounding error,
+# and the 1e10-long last interval turns that sign into a 0/1 opacity.  sigma_linear.bias += 1 (both
+# networks) moves every sigma_last away from zero, so that ALL rays can be compared through the 16-bit
+# kernels without a mask.  Same rays as F8 (only the maps are stored).
+pcb = {k: v.clone() for k, v in pc.items()}
+pfb = {k: v.clone() for k, v in pf.items()}
+pcb["sigma_linear.bias"] += 1.0
+pfb["sigma_linear.bias"] += 1.0
+meta["sha_coarse_seed0_sigma_bias1"] = O.params_sha256(pcb)
+meta["sha_fine_seed1_sigma_bias1"] = O.params_sha256(pfb)
+mcb, mfb = ref_model(pcb), ref_model(pfb)
+f8b = {}
+with torch.no_grad():
+    for lind in (False, True):
+        for wb in (False, True):
+            c = render_rays(mcb, pe10, pe4, ro, rd, 2.0, 6.0, 64, rand=False, lindisp=lind, white_bkgd=wb)
+            zm = 0.5 * (c["z_vals"][..., 1:] + c["z_vals"][..., :-1])
+            zs_f = sample_pdf(zm, c["weights"][..., 1:-1] + 1e-5, 128, det=True)
+            zc2, _ = torch.sort(torch.cat([c["z_vals"], zs_f], -1), -1)
+            f = render_rays(mfb, pe10, pe4, ro, rd, 2.0, 6.0, 192, rand=False, lindisp=lind, white_bkgd=wb,
+                            z_vals_override=zc2)
+            oc, of = O.render_hierarchical(pcb, pfb, ro, rd, 2.0, 6.0, 64, 128, det=True, lindisp=lind,
+                                           white_bkgd=wb)
+            tag = f"l{int(lind)}w{int(wb)}"
+            for k in ("rgb_map", "depth_map", "acc_map", "disp_map"):
+                eq(oc[k], c[k], f"e2e-b coarse {k} {tag}"); eq(of[k], f[k], f"e2e-b fine {k} {tag}")
+                f8b[f"c_{k}_{tag}"] = c[k]; f8b[f"f_{k}_{tag}"] = f[k]
+            f8b[f"c_sigma_last_min_{tag}"] = c["raw_sigma"][:, -1].abs().min()
+            f8b[f"f_sigma_last_min_{tag}"] = f["raw_sigma"][:, -1].abs().min()
+            if not lind and not wb:
+                f8b["z_comb_l0w0"] = zc2
+save("f8b_e2e_wellcond", **f8b)
+
+# ---- F10 checkpoints written by the reference's own classes -------------------------------------------
+# scripts/train_nerf.py:118-131 stores {epoch, global_step, args_saved_at_checkpoint = vars(args), H, W,
+# focal, model_coarse_state_dict, optimizer_state_dict[, model_fine_state_dict]} with torch.save.  The
+# script itself cannot be imported here (configargparse is absent), so the dict is assembled exactly as
+# those lines do, from the reference's NeRF class, torch.optim.Adam over coarse+fine parameters
+# (train_nerf.py:203-206) after two real optimizer steps, and a plain dict with the keys of
+# parse_args() (train_nerf.py:48-85).  Two small architectures: hierarchical with view directions, and
+# the script's DEFAULT flags (no view directions, coarse only).
+def ref_args(**over):
+    a = {"config": None, "expname": "fixture", "basedir": "./logs/", "dataset_path": "data/none",
+         "data_white_bkgd": False, "white_bkgd": False, "near": 2.0, "far": 6.0, "N_samples_coarse": 16,
+         "N_samples_fine": 24, "use_hierarchical": False, "lindisp": False, "num_epochs": 200,
+         "batch_size": 1024, "lr": 5e-4, "lr_decay_factor": 0.1, "lr_decay_steps": 250000, "seed": 42,
+         "num_workers": 4, "net_depth": 8, "net_width": 256, "input_ch_pts_L": 10, "input_ch_views_L": 4,
+         "use_viewdirs": False, "log_freq": 100, "save_freq": 10, "val_img_freq": 5000,
+         "resume_from_checkpoint": None}
+    a.update(over)
+    return a
+
+
+def make_ckpt(name, args, seed):
+    torch.manual_seed(seed)
+    use_v, hier = args["use_viewdirs"], args["use_hierarchical"]
+    pe_p = PositionalEncoder(3, args["input_ch_pts_L"])
+    pe_v = PositionalEncoder(3, args["input_ch_views_L"]) if use_v else None
+    kw = dict(D=args["net_depth"], W=args["net_width"], input_ch_pts=pe_p.output_dims,
+              input_ch_views=pe_v.output_dims if use_v else 0, skips=[args["net_depth"] // 2], use_viewdirs=use_v)
+    m_c = NeRF(**kw)
+    m_f = NeRF(**kw) if hier else None
+    params = list(m_c.parameters()) + (list(m_f.parameters()) if hier else [])
+    opt = torch.optim.Adam(params, lr=args["lr"])
+    n = 64
+    r_o, r_d = ro[:n], rd[:n]
+    tgt_ = U(n, 3)
+    nc, nf = args["N_samples_coarse"], args["N_samples_fine"]
+
+    def two_pass(rand, queue):
+        with PatchedRand(queue):
+            c = render_rays(m_c, pe_p, pe_v, r_o, r_d, 2.0, 6.0, nc, rand=rand, use_viewdirs=use_v)
+            f = None
+            if hier:
+                with torch.no_grad():
+                    zm = 0.5 * (c["z_vals"][..., 1:] + c["z_vals"][..., :-1])
+                    zs_ = sample_pdf(zm, c["weights"].detach()[..., 1:-1] + 1e-5, nf, det=not rand)
+                zc_, _ = torch.sort(torch.cat([c["z_vals"].detach(), zs_], -1), -1)
+                f = render_rays(m_f, pe_p, pe_v, r_o, r_d, 2.0, 6.0, nc + nf, rand=rand, use_viewdirs=use_v,
+                                z_vals_override=zc_)
+        return c, f
+
+    for _ in range(2):                                    # train_nerf.py:293-336
+        q = [U(n, nc)] + ([U(n, nf), U(n, nc + nf)] if hier else [])
+        c, f = two_pass(True, q)
+        loss = torch.mean((c["rgb_map"] - tgt_) ** 2)
+        if hier:
+            loss = loss + torch.mean((f["rgb_map"] - tgt_) ** 2)
+        opt.zero_grad(); loss.backward(); opt.step()
+    save_dict = {"epoch": 3, "global_step": 2, "args_saved_at_checkpoint": args, "H": 20, "W": 24, "focal": 30.0,
+                 "model_coarse_state_dict": m_c.state_dict(), "optimizer_state_dict": opt.state_dict()}
+    if hier:
+        save_dict["model_fine_state_dict"] = m_f.state_dict()
+    torch.save(save_dict, os.path.join(OUT, name + ".pth"))
+    # what the reference renders from these weights (render_nerf.py:275-303: rand=False, det=True)
+    with torch.no_grad():
+        c, f = two_pass(False, [])
+    out = {"rays_o": r_o, "rays_d": r_d, "c_rgb_map": c["rgb_map"], "c_depth_map": c["depth_map"],
+           "c_acc_map": c["acc_map"]}
+    if hier:
+        out.update({"f_rgb_map": f["rgb_map"], "f_depth_map": f["depth_map"], "f_acc_map": f["acc_map"]})
+    # one more reference optimizer step from the saved state: what a resumed run must reproduce
+    q = [U(n, nc)] + ([U(n, nf), U(n, nc + nf)] if hier else [])
+    out["t_rand_coarse"] = q[0]
+    if hier:
+        out["u_fine"], out["t_rand_fine"] = q[1], q[2]
+    out["target"] = tgt_
+    c, f = two_pass(True, q)
+    loss = torch.mean((c["rgb_map"] - tgt_) ** 2)
+    if hier:
+        loss = loss + torch.mean((f["rgb_map"] - tgt_) ** 2)
+    opt.zero_grad(); loss.backward(); opt.step()
+    out["loss_step3"] = loss.detach()
+    out["c_l0_bias_after_step3"] = m_c.pts_linears[0].bias.detach().clone()
+    out["c_last_weight_after_step3"] = (m_c.rgb_layers[2].weight if use_v else m_c.output_linear.weight).detach().clone()
+    save(name + "_render", **out)
+
+
+make_ckpt("f10_ckpt_hier_views", ref_args(net_depth=4, net_width=32, input_ch_pts_L=6, input_ch_views_L=2,
+                                          use_viewdirs=True, use_hierarchical=True), 7)
+make_ckpt("f10_ckpt_default_flags", ref_args(net_depth=4, net_width=32, input_ch_pts_L=6), 8)
+
+# ---- call signatures of the drop-in boundary ---------------------------------------------------------
+import inspect  # noqa: E402
+meta["signatures"] = {
+    "PositionalEncoder.__init__": str(inspect.signature(PositionalEncoder.__init__)),
+    "PositionalEncoder.forward": str(inspect.signature(PositionalEncoder.forward)),
+    "NeRF.__init__": str(inspect.signature(NeRF.__init__)),
+    "NeRF.forward": str(inspect.signature(NeRF.forward)),
+    "sample_pdf": str(inspect.signature(sample_pdf)),
+    "render_rays": str(inspect.signature(render_rays)),
+    "get_rays": str(inspect.signature(get_rays)),
+}
+
 with open(os.path.join(OUT, "meta.json"), "w") as fh:
     json.dump(meta, fh, indent=1, sort_keys=True)
 tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

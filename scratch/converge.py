@@ -38,7 +38,8 @@ root = tempfile.mkdtemp()
 make_scene(root)
 train, val = BlenderDataset(root, "train"), BlenderDataset(root, "val")
 for prec in ("bf16", "fp16"):
-    tr = Trainer(train, TrainConfig(basedir=root, expname="x" + prec, batch_size=1024, precision=prec, log_freq=500), log=print)
+    tr = Trainer(train, TrainConfig(basedir=root, expname="x" + prec, batch_size=1024, precision=prec, log_freq=500, use_hierarchical=True,
+                                    use_viewdirs=True), log=print)
     kw = dict(chunk=65536)
     p0 = evaluate(tr.model_coarse, tr.model_fine, tr.pe, tr.pv, val, **kw)["psnr"]
     t0 = time.time()

@@ -1,8 +1,10 @@
 """One rank of the two-rank data-parallel training check of test_gpu_system.py (launched by
 torch.distributed.run; both ranks share GPU 0 and talk over gloo).
 
-argv: out_dir mode, mode = "same" (both ranks hold the same rays and targets) or "split" (rank 1's
-targets differ).  Each rank saves its flat weights and per-step losses after three graph-replayed steps.
+argv: out_dir mode [backend], mode = "same" (both ranks hold the same rays and targets) or "split" (rank 1's
+targets differ); backend "gloo" (default: both ranks share GPU 0) or "nccl" (RCCL, one GPU per rank).  Each
+rank saves its flat weights and per-step losses after three graph-replayed steps, and under nccl also a
+row-sharded, all-gathered frame.
 """
 import os
 import sys
@@ -32,12 +34,28 @@ def run_steps(world, rank, mode, n=256, steps=3):
     return opt.flat.detach().cpu(), losses
 
 
+def render_frame(rank, world, H=96, W=64):
+    """one frame, rows sharded over the ranks, gathered on every rank"""
+    import nerf_amd
+    from nerf_amd.render import render_image
+    from nerf_amd.utils.synthetic import focal_from_fov, pose_spherical
+    dev = "cuda"
+    mc, mf = amd_model(O.init_params(0), "fp16"), amd_model(O.init_params(1), "fp16")
+    pe, pv = nerf_amd.PositionalEncoder(3, 10).to(dev), nerf_amd.PositionalEncoder(3, 4).to(dev)
+    return render_image(mc, mf, pe, pv, H, W, focal_from_fov(W), pose_spherical(25.0, -30.0, 4.0).to(dev), chunk=1500,
+                        rank=rank, world_size=world)
+
+
 if __name__ == "__main__":
     out_dir, mode = sys.argv[1], sys.argv[2]
+    backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
     from nerf_amd.parallel import init_distributed
-    rank, world, _ = init_distributed("gloo")
+    rank, world, _ = init_distributed(backend)
     flat, losses = run_steps(world, rank, mode)
-    torch.save({"flat": flat, "losses": losses}, os.path.join(out_dir, f"{mode}_rank{rank}.pt"))
+    out = {"flat": flat, "losses": losses}
+    if backend == "nccl":
+        out["frame"] = render_frame(rank, world).cpu()
+    torch.save(out, os.path.join(out_dir, f"{mode}_rank{rank}.pt"))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()

@@ -128,7 +128,7 @@ def test_trainer_checkpoint_resume(tmp_path):
     make_blender_scene(root, n_images=4, H=16, W=16, channels=4, splits=("train",))
     ds = BlenderDataset(root, "train", data_white_bkgd=True)
     cfg = TrainConfig(expname="t", basedir=str(tmp_path / "logs"), batch_size=256, log_freq=5, save_freq=1,
-                      white_bkgd=True, precision="fp16", lr=1e-3)
+                      white_bkgd=True, precision="fp16", lr=1e-3, use_hierarchical=True, use_viewdirs=True)
     logs = []
     tr = Trainer(ds, cfg, log=logs.append)
     assert tr.steps_per_epoch == 4                                   # 4 images * 256 px / 256 rays
@@ -173,7 +173,8 @@ def test_training_learns_a_scene_and_generalises(tmp_path, precision):
     make_sphere_scene(str(tmp_path))
     train, val = BlenderDataset(str(tmp_path), "train"), BlenderDataset(str(tmp_path), "val")
     tr = Trainer(train, TrainConfig(basedir=str(tmp_path), expname="sphere", batch_size=1024, precision=precision,
-                                    log_freq=500, save_freq=10 ** 6), log=None)
+                                    log_freq=500, save_freq=10 ** 6, use_hierarchical=True, use_viewdirs=True),
+                 log=None)
     before = evaluate(tr.model_coarse, tr.model_fine, tr.pe, tr.pv, val)["psnr"]
     tr.fit(num_epochs=10 ** 6, max_steps=1500)
     after = evaluate(tr.model_coarse, tr.model_fine, tr.pe, tr.pv, val)["psnr"]

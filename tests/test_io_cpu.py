@@ -1,5 +1,7 @@
 """CPU tests of the file formats either side of the hot path: PNG IO, the checkpoint wire format of
 scripts/train_nerf.py:118-131, and the loader oracle's blend arithmetic."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -104,3 +106,134 @@ def test_learning_rate_schedule():
     assert abs(learning_rate(cfg, 250000) - 5e-5) < 1e-12          # train_nerf.py:288
     assert abs(learning_rate(cfg, 125000) - 5e-4 * 0.1 ** 0.5) < 1e-12
     assert abs(mse_to_psnr(0.01) - 20.0) < 1e-9
+
+
+def test_pose_spherical_known_answers():
+    """scripts/render_nerf.py:72-124 cannot be imported here (configargparse is absent), so the product's and
+    the oracle's pose_spherical are pinned by values worked out by hand from those lines:
+    c2w = shift_y(h) @ R_y(theta) @ R_x(phi) @ T_z(r)."""
+    import math
+    from util import O
+    from nerf_amd.utils.synthetic import camera_path, pose_spherical
+    for fn in (pose_spherical, O.pose_spherical):
+        # theta = phi = 0: the identity rotation, camera at (0, 0, r)
+        p = fn(0.0, 0.0, 4.0)
+        assert torch.allclose(p, torch.tensor([[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0], [0, 0, 0, 1]]), atol=1e-7)
+        # theta = 90: R_y maps z to x, so the camera sits at (r, 0, 0) and its x axis points along -z
+        p = fn(90.0, 0.0, 4.0)
+        want = torch.tensor([[0.0, 0, 1, 4.0], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 0, 1]])
+        assert torch.allclose(p, want, atol=1e-6)
+        # phi = -90: R_x(-90) maps z to -y... row 1 = (0, cos, -sin) = (0, 0, 1): camera at (0, r, 0)
+        p = fn(0.0, -90.0, 4.0)
+        want = torch.tensor([[1.0, 0, 0, 0], [0, 0, 1, 4.0], [0, -1, 0, 0], [0, 0, 0, 1]])
+        assert torch.allclose(p, want, atol=1e-6)
+        # the benchmark's elevation with a vertical shift: position r (0, sin 30, cos 30) + (0, h, 0)
+        p = fn(0.0, -30.0, 4.0, 0.5)
+        assert torch.allclose(p[:3, 3], torch.tensor([0.0, 4 * 0.5 + 0.5, 4 * math.cos(math.radians(30))]), atol=1e-6)
+        assert p.dtype == torch.float32 and torch.allclose(p[:3, :3] @ p[:3, :3].T, torch.eye(3), atol=1e-6)
+    path = camera_path(120)                                            # render_nerf.py:145-149
+    assert path.shape == (120, 4, 4)
+    assert torch.allclose(path[30], O.pose_spherical(90.0, -30.0, 4.0), atol=1e-6)
+    assert torch.equal(path[0], pose_spherical(0.0, -30.0, 4.0))
+
+
+def test_signatures_match_the_reference():
+    """positional parameters (names, order, defaults) of the five boundary symbols against the strings
+    inspect.signature gave for the reference's own objects (oracle/gen_golden.py -> meta.json); the product
+    may add keyword-only parameters and constructor keywords with defaults after the reference's."""
+    import inspect
+    import json
+    import re
+    import nerf_amd
+    from util import ROOT
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "meta.json")))["signatures"]
+
+    def ref_params(sig):
+        inner = sig[sig.index("(") + 1: sig.rindex(")")]
+        out, depth, cur = [], 0, ""
+        for ch in inner:                       # split on top-level commas
+            depth += ch in "[(" ; depth -= ch in "])"
+            if ch == "," and depth == 0:
+                out.append(cur); cur = ""
+            else:
+                cur += ch
+        out.append(cur)
+        res = []
+        for p in out:
+            name = re.split(r"[:=]", p.strip())[0].strip()
+            default = p.split("=")[-1].strip() if "=" in p else None
+            res.append((name, default))
+        return res
+
+    objs = {"PositionalEncoder.__init__": nerf_amd.PositionalEncoder.__init__,
+            "PositionalEncoder.forward": nerf_amd.PositionalEncoder.forward,
+            "NeRF.__init__": nerf_amd.NeRF.__init__, "NeRF.forward": nerf_amd.NeRF.forward,
+            "sample_pdf": nerf_amd.sample_pdf, "render_rays": nerf_amd.render_rays, "get_rays": nerf_amd.get_rays}
+    for name, obj in objs.items():
+        want = ref_params(meta[name])
+        got = [(p.name, None if p.default is inspect.Parameter.empty else repr(p.default))
+               for p in inspect.signature(obj).parameters.values()
+               if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        assert [g[0] for g in got[:len(want)]] == [w[0] for w in want], (name, got, want)
+        for (gn, gd), (wn, wd) in zip(got, want):
+            assert (gd is None) == (wd is None) and (gd is None or gd == wd), (name, gn, gd, wd)
+        for extra in got[len(want):]:
+            assert extra[1] is not None, (name, "added positional parameter without a default", extra)
+
+
+@pytest.mark.parametrize("name", ["f10_ckpt_hier_views", "f10_ckpt_default_flags"])
+def test_reference_checkpoint_fixture_loads_and_oracle_renders_it(name):
+    """The checkpoint fixtures were written by the reference's NeRF class and torch.optim.Adam in the layout of
+    scripts/train_nerf.py:118-131.  Here (CPU): the safe loader accepts them, the dict has the reference's keys,
+    and the oracle renders the stored weights to the maps the reference rendered."""
+    import numpy as np
+    from util import O, ROOT, T
+    from nerf_amd import checkpoint as C
+    gdir = os.path.join(ROOT, "tests", "golden")
+    ck = C.load_checkpoint(os.path.join(gdir, name + ".pth"))
+    g = dict(np.load(os.path.join(gdir, name + "_render.npz")))
+    a = ck["args_saved_at_checkpoint"]
+    hier, views = a["use_hierarchical"], a["use_viewdirs"]
+    want = {"epoch", "global_step", "args_saved_at_checkpoint", "H", "W", "focal", "model_coarse_state_dict",
+            "optimizer_state_dict"} | ({"model_fine_state_dict"} if hier else set())
+    assert set(ck.keys()) == want
+    assert set(a.keys()) >= {"expname", "basedir", "dataset_path", "near", "far", "net_depth", "use_viewdirs", "lr"}
+    arch = dict(D=a["net_depth"], skips=(a["net_depth"] // 2,), use_viewdirs=views, L_pts=a["input_ch_pts_L"],
+                L_views=a["input_ch_views_L"])
+    shapes = O.param_shapes(D=a["net_depth"], W=a["net_width"], input_ch_pts=3 + 6 * a["input_ch_pts_L"],
+                            input_ch_views=3 + 6 * a["input_ch_views_L"] if views else 0, skips=arch["skips"],
+                            use_viewdirs=views)
+    assert [(k, tuple(v.shape)) for k, v in ck["model_coarse_state_dict"].items()] == shapes
+    n_par = len(shapes) * (2 if hier else 1)
+    assert len(ck["optimizer_state_dict"]["state"]) == n_par
+    assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 2.0
+    ro, rd = T(g["rays_o"]), T(g["rays_d"])
+    nc, nf = a["N_samples_coarse"], a["N_samples_fine"]
+    with torch.no_grad():
+        if hier:
+            c, f = O.render_hierarchical(ck["model_coarse_state_dict"], ck["model_fine_state_dict"], ro, rd, 2.0, 6.0,
+                                         nc, nf, det=True, **arch)
+        else:
+            c, f = O.render_rays(ck["model_coarse_state_dict"], ro, rd, 2.0, 6.0, nc, **arch), None
+    for k in ("rgb_map", "depth_map", "acc_map"):
+        assert (c[k] - T(g[f"c_{k}"])).abs().max() < 1e-5
+        if f is not None:
+            assert (f[k] - T(g[f"f_{k}"])).abs().max() < 1e-4
+    # build_models on the CPU: the architecture of render_nerf.py:188-252
+    mc, mf, pe, pv, cfg = C.build_models(ck, device="cpu")
+    assert (mf is not None) == hier and (pv is not None) == views and cfg["precision"] == "fp32"
+
+
+def test_wellconditioned_fixture_matches_oracle(golden):
+    """F8b (sigma_linear.bias += 1): the oracle reproduces the reference's maps on every ray."""
+    from util import O, T
+    g, e = golden("f8b_e2e_wellcond"), golden("f8_e2e_render")
+    pc, pf = O.init_params(0), O.init_params(1)
+    pc["sigma_linear.bias"] = pc["sigma_linear.bias"] + 1.0
+    pf["sigma_linear.bias"] = pf["sigma_linear.bias"] + 1.0
+    with torch.no_grad():
+        c, f = O.render_hierarchical(pc, pf, T(e["rays_o"]), T(e["rays_d"]), 2.0, 6.0, 64, 128, det=True, lindisp=True,
+                                     white_bkgd=True)
+    for k in ("rgb_map", "depth_map", "acc_map"):
+        assert (c[k] - T(g[f"c_{k}_l1w1"])).abs().max() < 1e-4
+        assert (f[k] - T(g[f"f_{k}_l1w1"])).abs().max() < 1e-3
