@@ -186,6 +186,19 @@ int64_t nerf_mlp_encoded_workspace_bytes(int64_t n_samples);
 int nerf_mlp_fwd_encoded(int64_t M, const float *x_pts, const float *x_views, const void *packed,
                          int precision, float *raw, void *saved, void *workspace, void *stream);
 
+/* The same forward as nerf_mlp_fwd_encoded(saved = NULL) with the workspace inside the library.  It has no
+ * counterpart in the reference: it exists for callers that cannot allocate device memory -- code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The call allocates nothing
+ * (no hipMalloc / hipFree, no allocating library routine): its staging buffer is a static device array of
+ * 12 MiB that every GPU the library runs on holds until the process ends, so M is limited to
+ * NERF_MLP_FWD_ENCODED_STATIC_MAX samples (NERF_E_SHAPE beyond that).  Results are bit-identical to
+ * nerf_mlp_fwd_encoded.  All calls on one GPU share the one array: calls that overlap in time on the same
+ * GPU (two streams, two threads) race; calls on one stream are ordered by the stream. */
+#define NERF_MLP_FWD_ENCODED_STATIC_MAX 65536
+int64_t nerf_mlp_fwd_encoded_static_max_samples(void);
+int nerf_mlp_fwd_encoded_static(int64_t M, const float *x_pts, const float *x_views, const void *packed,
+                                int precision, float *raw, void *stream);
+
 /* Backward: d_raw [M,4] -> d_params flat fp32 [NERF_MLP_NPARAMS] (overwritten,
  * not accumulated).  saved is what nerf_mlp_fwd wrote for the same samples.
  * grad_scale (nullable): one device float s; the incoming gradient is multiplied

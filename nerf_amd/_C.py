@@ -41,6 +41,8 @@ _SIGS = {
     "nerf_mlp_fwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P, P]),
     "nerf_mlp_encoded_workspace_bytes": (c_int64, [c_int64]),
     "nerf_mlp_fwd_encoded": (c_int, [c_int64, P, P, P, c_int, P, P, P, P]),
+    "nerf_mlp_fwd_encoded_static_max_samples": (c_int64, []),
+    "nerf_mlp_fwd_encoded_static": (c_int, [c_int64, P, P, P, c_int, P, P]),
     "nerf_mlp_bwd": (c_int, [c_int64, P, P, c_int, P, P, P, c_int64, P, P]),
     "nerf_mlp_dz_bytes": (c_int64, [c_int64]),
     "nerf_mlp_partial_bytes": (c_int64, [c_int64]),

@@ -7,6 +7,7 @@
 // fragment the chain produces is also stored as a [32 samples][16 positions] unit -- the format the
 // weight-gradient pass reads -- together with one sign bit per activation for the backward-data chain:
 // 4.7 KiB per sample, which is what bounds this kernel.  Layout and schedule: mlp_common.hpp, mlp_chain.hpp.
+#include <mutex>
 #include <type_traits>
 #include "mlp_chain.hpp"
 
@@ -308,15 +309,8 @@ extern "C" int64_t nerf_mlp_encoded_workspace_bytes(int64_t M) {
     return n_tiles * 8 * (int64_t)(PE_KS + VPE_KS) * 1024;
 }
 
-extern "C" int nerf_mlp_fwd_encoded(int64_t M, const float* x_pts, const float* x_views, const void* packed,
-                                    int precision, float* raw, void* saved, void* workspace, void* stream) {
-    NERF_REQUIRE(x_pts && x_views && packed && raw, NERF_E_NULL);
-    NERF_REQUIRE(saved || workspace, NERF_E_NULL);
-    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
-    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
-                 nerf_aligned(workspace, 256), NERF_E_ALIGN);
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
-    if (M == 0) return NERF_OK;
+static int fwd_encoded_impl(int64_t M, const float* x_pts, const float* x_views, const void* packed, int precision,
+                            float* raw, void* saved, void* workspace, void* stream) {
     FwdArgs a{};
     a.M = M; a.n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES; a.S = 1;
     a.packed = (const char*)packed; a.raw = raw; a.saved = (char*)saved;
@@ -338,4 +332,66 @@ extern "C" int nerf_mlp_fwd_encoded(int64_t M, const float* x_pts, const float* 
     const int rc = nerf_launch_status();
     if (rc) return rc;
     return launch_fwd(a, precision, true, stream);
+}
+
+extern "C" int nerf_mlp_fwd_encoded(int64_t M, const float* x_pts, const float* x_views, const void* packed,
+                                    int precision, float* raw, void* saved, void* workspace, void* stream) {
+    NERF_REQUIRE(x_pts && x_views && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(saved || workspace, NERF_E_NULL);
+    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
+    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
+                 nerf_aligned(workspace, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    if (M == 0) return NERF_OK;
+    return fwd_encoded_impl(M, x_pts, x_views, packed, precision, raw, saved, workspace, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same forward with its workspace in a static device array: an entry point that allocates nothing,
+// for callers that cannot (HIP graph capture, serving loops).  The array is the fragment-unit staging
+// buffer of nerf_mlp_fwd_encoded for at most NERF_MLP_FWD_ENCODED_STATIC_MAX samples (12 MiB); every
+// GPU the library runs on holds its own copy until the process ends.  All of the part a call reads is
+// written by that call's first kernel, so nothing has to start at zero; calls that overlap on one GPU
+// (different streams or threads) share the array and race.
+// ------------------------------------------------------------------------------------------------
+constexpr int64_t STATIC_MAX_TILES = (NERF_MLP_FWD_ENCODED_STATIC_MAX + TILE_SAMPLES - 1) / TILE_SAMPLES;
+constexpr int64_t STATIC_SCRATCH_BYTES = STATIC_MAX_TILES * 8 * (int64_t)(PE_KS + VPE_KS) * 1024;
+static __device__ __align__(256) char scratch[STATIC_SCRATCH_BYTES];
+
+// In host code `scratch` is only a handle for the symbol, not a device address: the address on each
+// device comes from hipGetSymbolAddress with that device current, and is kept per device.
+constexpr int MAX_DEVICES = 64;
+static void* g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+static int scratch_address(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    NERF_REQUIRE(dev >= 0 && dev < MAX_DEVICES, NERF_E_SHAPE);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        NERF_REQUIRE(p != nullptr, NERF_E_NULL);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return NERF_OK;
+}
+
+extern "C" int64_t nerf_mlp_fwd_encoded_static_max_samples(void) { return NERF_MLP_FWD_ENCODED_STATIC_MAX; }
+
+extern "C" int nerf_mlp_fwd_encoded_static(int64_t M, const float* x_pts, const float* x_views, const void* packed,
+                                           int precision, float* raw, void* stream) {
+    NERF_REQUIRE(x_pts && x_views && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(M >= 0 && M <= NERF_MLP_FWD_ENCODED_STATIC_MAX, NERF_E_SHAPE);      // beyond the static buffer
+    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256), NERF_E_ALIGN);
+    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    if (M == 0) return NERF_OK;
+    void* ws = nullptr;
+    const int rc = scratch_address(&ws);
+    if (rc) return rc;
+    return fwd_encoded_impl(M, x_pts, x_views, packed, precision, raw, nullptr, ws, stream);
 }
