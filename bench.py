@@ -11,7 +11,10 @@ runs that step on its own rays (weak scaling) and the gradients are summed with 
 all-reduce of the flat 4.77 MB bucket before the optimizer step.  Inputs are synthetic (seeded
 Blender-style camera, random-init weights, uniform targets) and resident in HBM.
 
-Rank 0 prints one JSON line.  `value` = rays processed by all ranks / wall time (max over ranks).
+Rank 0 prints one JSON line.  `value` = rays processed by all ranks / wall time (max over ranks) of the
+median of --repeats timed regions of exactly --steps steps each.  The line also carries the same step at
+4096 rays per GPU (the data-parallel configuration's batch) and, for N > 1, a row-sharded 800x800 frame render
+with its all_gather and a frame-sharded slice of the 120-pose camera path.
 The timed steps replay the step from HIP graphs (a 1024-ray step is 28 short launches; issued from
 Python the host would be the bottleneck).  `roofline` describes the kernel with the largest share of
 GPU time in the step; its duration comes from HIP events recorded on the launch stream around every
@@ -33,6 +36,8 @@ sys.path.insert(0, ROOT)
 MLP_FWD_FLOP = 1186816          # 2 * 593 408 MAC per sample, unpadded dims
 MLP_DGRAD_FLOP = 2 * 557696     # backward-data MACs per sample (view/point-encoding inputs need none)
 MLP_WGRAD_FLOP = 2 * 593408
+MLP_FLOP_PER_RAY_TRAIN = 256 * (MLP_FWD_FLOP + MLP_DGRAD_FLOP + MLP_WGRAD_FLOP)   # 64 + 192 evaluations: 893.2 MFLOP
+MLP_FLOP_PER_RAY_RENDER = 256 * MLP_FWD_FLOP                                       # 303.8 MFLOP
 MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 peak, MI355X
 HBM_PEAK_GBS = 8000.0
 WGRAD_BYTES_PER_SAMPLE = 280 * 1024 // 32   # saved activations (142 KiB) + dZ (138 KiB) per 32 samples, each read once
@@ -74,6 +79,10 @@ def parse():
                     help="torch.distributed backend (default: nccl = RCCL on GPUs); gloo lets several ranks share one GPU "
                          "to rehearse the N>1 code path")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch from Python instead of replaying HIP graphs")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed region of --steps steps is run this many times; the median region is reported")
+    ap.add_argument("--big-batch", type=int, default=4096,
+                    help="rays per GPU of the second training measurement (the data-parallel configuration's batch); 0 = skip")
     ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
     return ap.parse_args()
 
@@ -114,7 +123,10 @@ def render_section(mc, mf, pe, pv, device, args):
         torch.cuda.synchronize()
         times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
         sec = {"workload": "800x800 frame, 640000 rays, 64+128 samples, chunk %d, no_grad, deterministic" % chunk,
-               "s_per_frame": round(dt, 4), "rays_per_s": round(H * W / dt, 1), "kernels": {}}
+               "s_per_frame": round(dt, 4), "rays_per_s": round(H * W / dt, 1),
+               # the whole render against the dense MFMA peak: 256 evaluations x 1 186 816 FLOP per ray
+               "mlp_flop_frac_of_mfma_peak": round(H * W / dt * MLP_FLOP_PER_RAY_RENDER / (MFMA_PEAK_TFLOPS * 1e12), 4),
+               "kernels": {}}
         for name, evs in sorted(times.items()):
             tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
             units = sum(u for _, _, u in evs)
@@ -188,7 +200,8 @@ def whole_frame_kernels(device):
             del raw, z, g_rgb, d_raw
         c2w = torch.eye(4, device=device)[:3].contiguous()
         out["get_rays_800x800"] = rate(lambda: ops.get_rays(800, 800, 1111.0, c2w), n * 24, iters=20)
-        out["get_rays_3200x3200"] = rate(lambda: ops.get_rays(3200, 3200, 4444.0, c2w), 16 * n * 24)
+        # 983 MB written per launch: four times the 256 MB infinity cache, so this is the HBM rate
+        out["get_rays_6400x6400"] = rate(lambda: ops.get_rays(6400, 6400, 8888.0, c2w), 64 * n * 24)
     return out
 
 
@@ -199,7 +212,7 @@ def one_eighth_gpu(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-one-eighth", "--steps", "20",
            "--warmup", "5", "--rays-per-gpu", str(args.rays_per_gpu), "--precision", args.precision,
-           "--render-chunk", str(args.render_chunk[0])]
+           "--render-chunk", str(args.render_chunk[0]), "--big-batch", "0", "--repeats", "1"]
     env = dict(os.environ, HSA_CU_MASK="0:0-31")
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -268,36 +281,20 @@ def stage(msg):
         print("[bench rank %s] %.2f %s" % (os.environ.get("RANK", "0"), time.time() % 1000, msg), file=sys.stderr, flush=True)
 
 
-def main():
-    args = parse()
-    if os.environ.get("NERF_BENCH_TRACE"):
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["NERF_BENCH_TRACE"]), exit=False)     # where a hung rank is
-    from nerf_amd.parallel import init_distributed
-    rank, world, local_rank = init_distributed(args.dist_backend)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    device = torch.device("cuda", torch.cuda.current_device())
+def train_leg(args, n, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_ranks, kernel_steps, step0=0):
+    """One training measurement at n rays per GPU: graphs captured, args.warmup untimed steps, then args.repeats
+    timed regions of exactly args.steps steps, each bracketed by barrier + synchronize on both sides and taken as
+    the maximum over ranks; the median region is the one reported.  With kernel_steps > 0 the same step is then
+    issued eagerly with HIP events on the launch stream around every C-ABI call."""
     import torch.distributed as dist
     from nerf_amd import ops
-    from nerf_amd.parallel import broadcast_parameters_
+    from nerf_amd.train import TrainStep
     from nerf_amd.utils.synthetic import synthetic_rays
-
-    n = args.rays_per_gpu
-    mc, mf, pe, pv, opt = build(device, args.precision)
-    broadcast_parameters_(opt.flat, world)
     rays_o, rays_d = synthetic_rays(n, device, seed=rank)
     target = torch.rand(n, 3, generator=torch.Generator().manual_seed(1000 + rank)).to(device)
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    from nerf_amd.train import TrainStep
-    step_fn = TrainStep(mc, mf, pe, pv, opt, n, near=2.0, far=6.0, N_samples_coarse=64, N_samples_fine=128,
-                        world_size=world, use_graph=not args.no_graph)
-
+    mk = lambda graph: TrainStep(mc, mf, pe, pv, opt, n, near=2.0, far=6.0, N_samples_coarse=64, N_samples_fine=128,
+                                 world_size=world, use_graph=graph)
+    step_fn = mk(not args.no_graph)
     # the batch sits in the step's own input buffers, where a loader's gather kernel writes it
     # (Trainer.train_step), so a step issues no input copies
     step_fn.rays_o.copy_(rays_o); step_fn.rays_d.copy_(rays_d); step_fn.target.copy_(target)
@@ -318,39 +315,137 @@ def main():
         if failed.item() > 0:
             graph_error = graph_error or "graph capture failed on another rank"
             print("bench.py: " + graph_error + "; continuing without graphs", file=sys.stderr, flush=True)
-            step_fn = TrainStep(mc, mf, pe, pv, opt, n, near=2.0, far=6.0, N_samples_coarse=64, N_samples_fine=128,
-                                world_size=world, use_graph=False)
+            step_fn = mk(False)
+            step_fn.rays_o.copy_(rays_o); step_fn.rays_d.copy_(rays_d); step_fn.target.copy_(target)
+            rays_o, rays_d, target = step_fn.rays_o, step_fn.rays_d, step_fn.target
     stage("graphs captured" if graph_error is None else "no graphs")
 
     def lr_at(i):      # scripts/train_nerf.py:288: lr0 * decay^(step / decay_steps)
         return 5e-4 * (0.1 ** (i / 250000.0))
 
-    stage("models built, parameters broadcast")
-    for s in range(args.warmup):
-        step_fn(rays_o, rays_d, target, lr=lr_at(s))
-        stage("warm-up step %d issued" % s)
+    it = step0
+    for _ in range(args.warmup):
+        step_fn(rays_o, rays_d, target, lr=lr_at(it)); it += 1
+    regions = []
+    loss = None
+    for _ in range(max(1, args.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step_fn(rays_o, rays_d, target, lr=lr_at(it)); it += 1
+        sync()
+        regions.append(max_over_ranks(time.perf_counter() - t0))
+        stage("timed region done")
+    if not torch.isfinite(loss).item():
+        raise SystemExit("non-finite loss")
+    dt = sorted(regions)[len(regions) // 2]
+    times = None
+    if kernel_steps > 0:
+        # per-kernel durations: the same step issued eagerly with HIP events on the launch stream
+        step_fn.use_graph = False
+        step_fn(rays_o, rays_d, target, lr=lr_at(it)); it += 1
+        ops.KERNEL_TIMES = {}
+        for _ in range(kernel_steps):
+            step_fn(rays_o, rays_d, target, lr=lr_at(it)); it += 1
+        sync()
+        times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+    return {"dt": dt, "regions_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
+            "graph_error": graph_error, "times": times, "next_step": it}
+
+
+def render_sharded_section(mc, mf, pe, pv, device, args, rank, world, sync, max_over_ranks):
+    """The two multi-GPU render measurements: (i) one 800x800 frame cut into row blocks, one per rank, assembled
+    by one all_gather (render_nerf.py:260-307 per frame); (ii) frames of the 120-pose camera path with the white
+    background and inverse-depth sampling dealt to the ranks, four per rank, no collective
+    (render_nerf.py:145-149).  Times are the maximum over ranks between barriers."""
+    from nerf_amd.parallel import gather_rows, shard_rows
+    from nerf_amd.render import render_image, render_path
+    from nerf_amd.utils.synthetic import camera_path, focal_from_fov, pose_spherical
+    H = W = 800
+    chunk = args.render_chunk[0]
+    focal = focal_from_fov(W)
+    c2w = pose_spherical(0.0, -30.0, 4.0).to(device)
+    render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=chunk, rank=rank, world_size=world)      # warm-up
+    frames = 3
     sync()
-    stage("warm-up done")
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        loss = step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + s))
-        stage("timed step %d issued" % s)
+    for _ in range(frames):
+        render_image(mc, mf, pe, pv, H, W, focal, c2w, chunk=chunk, rank=rank, world_size=world)
     sync()
-    dt = time.perf_counter() - t0
-    stage("timed region done")
-    # per-kernel durations: the same step issued eagerly with HIP events on the launch stream
-    step_fn.use_graph = False
-    step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + args.steps))
-    ops.KERNEL_TIMES = {}
-    for s in range(args.kernel_steps):
-        step_fn(rays_o, rays_d, target, lr=lr_at(args.warmup + args.steps + 1 + s))
+    dt = max_over_ranks(time.perf_counter() - t0) / frames
+    block = torch.zeros((shard_rows(H, rank, world)[1], W, 3), device=device)
+    gather_rows(block, H, rank, world)
     sync()
-    times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+    t0 = time.perf_counter()
+    for _ in range(10):
+        gather_rows(block, H, rank, world)
+    torch.cuda.synchronize()
+    gather_us = max_over_ranks(time.perf_counter() - t0) / 10 * 1e6
+    out = [{"workload": "800x800 frame, 640000 rays, 64+128 samples, chunk %d, no_grad, deterministic, image rows "
+                        "sharded over %d ranks, one all_gather of the colour blocks" % (chunk, world),
+            "s_per_frame": round(dt, 5), "rays_per_s": round(H * W / dt, 1), "all_gather_us": round(gather_us, 1),
+            "all_gather_bytes": H * W * 12,
+            "mlp_flop_frac_of_mfma_peak": round(H * W / dt * MLP_FLOP_PER_RAY_RENDER / (world * MFMA_PEAK_TFLOPS * 1e12), 4)}]
+    per_rank = 4
+    n_frames = per_rank * world
+    idx = [int(i * 120 / n_frames) for i in range(n_frames)]
+    poses = camera_path(120).to(device)[idx]
+    render_path(mc, mf, pe, pv, H, W, focal, poses[:1], chunk=chunk, lindisp=True, white_bkgd=True)     # warm-up
+    sync()
+    t0 = time.perf_counter()
+    got = render_path(mc, mf, pe, pv, H, W, focal, poses, chunk=chunk, lindisp=True, white_bkgd=True,
+                      rank=rank, world_size=world)
+    sync()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    out.append({"workload": "camera path: %d of the 120 poses (%d per rank, dealt round-robin, no collective), 800x800, "
+                            "64+128 samples, lindisp, white background, chunk %d, uint8 frames on the host"
+                            % (n_frames, per_rank, chunk),
+                "frames_per_s": round(n_frames / dt, 3), "rays_per_s": round(n_frames * H * W / dt, 1),
+                "s_per_frame_per_rank": round(dt / per_rank, 5), "frames_this_rank": len(got),
+                "mlp_flop_frac_of_mfma_peak": round(n_frames * H * W / dt * MLP_FLOP_PER_RAY_RENDER
+                                                    / (world * MFMA_PEAK_TFLOPS * 1e12), 4)})
+    return out
+
+
+def main():
+    args = parse()
+    if os.environ.get("NERF_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NERF_BENCH_TRACE"]), exit=False)     # where a hung rank is
+    from nerf_amd.parallel import init_distributed
+    rank, world, local_rank = init_distributed(args.dist_backend)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    device = torch.device("cuda", torch.cuda.current_device())
+    import torch.distributed as dist
+    from nerf_amd.parallel import all_reduce_, broadcast_parameters_
+
+    n = args.rays_per_gpu
+    mc, mf, pe, pv, opt = build(device, args.precision)
+    broadcast_parameters_(opt.flat, world)
+    stage("models built, parameters broadcast")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        return float(all_reduce_(torch.tensor([x], dtype=torch.float64, device=device), op=dist.ReduceOp.MAX).item())
+
+    leg = train_leg(args, n, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_ranks, args.kernel_steps)
+    dt, times, graph_error = leg["dt"], leg["times"], leg["graph_error"]
+    big = None
+    if args.big_batch and args.big_batch != n:
+        # the data-parallel configuration's batch (4096 rays per GPU), measured at every N so that its own
+        # scaling curve exists; the headline value stays at the same per-GPU batch for every N
+        big = train_leg(args, args.big_batch, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_ranks, 0,
+                        step0=leg["next_step"])
     allreduce_us = None
     if world > 1:
-        from nerf_amd.parallel import all_reduce_
-        dt = float(all_reduce_(torch.tensor([dt], dtype=torch.float64, device=device), op=dist.ReduceOp.MAX).item())
-        # the collective on its own: the whole gradient bucket, back to back, after the timed region
+        # the collective on its own: the whole gradient bucket, back to back, after the timed regions
         scratch_bucket = torch.zeros_like(opt.flat_grad)
         all_reduce_(scratch_bucket)
         sync()
@@ -359,11 +454,12 @@ def main():
             all_reduce_(scratch_bucket)
         torch.cuda.synchronize()
         allreduce_us = (time.perf_counter() - t1) / 10 * 1e6
-    if not torch.isfinite(loss).item():
-        raise SystemExit("non-finite loss")
+    render_sharded = None
+    if world > 1 and not args.no_render:
+        render_sharded = render_sharded_section(mc, mf, pe, pv, device, args, rank, world, sync, max_over_ranks)
 
     if rank == 0:
-        # per-kernel GPU time inside the timed region (HIP events on the launch stream)
+        # per-kernel GPU time of the step (HIP events on the launch stream)
         ktime = {}
         for name, evs in times.items():
             tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
@@ -372,6 +468,7 @@ def main():
                 "mlp_bwd_weights": MLP_WGRAD_FLOP}
         dom = max((k for k in ktime if k in flop), key=lambda k: ktime[k][3])
         avg_ms, launches, units, tot_ms = ktime[dom]
+        mfma_kernel = units * flop[dom] / (avg_ms * 1e-3) / 1e12
         if dom == "mlp_bwd_weights":
             # the weight-gradient pass contracts over samples: every saved-activation unit and every dZ
             # unit is read once, 280 KiB per 32 samples; it is HBM-bound in this design
@@ -379,14 +476,20 @@ def main():
             rl = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_sample": WGRAD_BYTES_PER_SAMPLE}
         else:
-            achieved = units * flop[dom] / (avg_ms * 1e-3) / 1e12
-            rl = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flop[dom]}
+            rl = {"bound": "mfma", "achieved": round(mfma_kernel, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(mfma_kernel / MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flop[dom]}
+        rays_per_s = n * world * args.steps / dt
         traffic = measured_traffic(dom, n, args.precision)
         roofline = {"kernel": dom, **rl, "traffic": traffic,
                     "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 PMC passes of this "
                                     "command, profiles/traffic.json" if traffic is not None else "not collected",
                     "algorithmic_bytes_per_launch": round(units * WGRAD_BYTES_PER_SAMPLE) if rl["bound"] == "hbm" else None,
+                    # the same kernel and the whole step against the dense MFMA peak, with the reference
+                    # algorithm's unpadded FLOP counts (2 x 593 408 per sample for the weight gradients;
+                    # 893.2 MFLOP per ray for forward + backward of the 64 + 192 evaluations)
+                    "mfma_frac_kernel": round(mfma_kernel / MFMA_PEAK_TFLOPS, 4),
+                    "step_mfma_frac": round(rays_per_s * MLP_FLOP_PER_RAY_TRAIN / (world * MFMA_PEAK_TFLOPS * 1e12), 4),
+                    "mlp_flop_per_ray_fwd_bwd": MLP_FLOP_PER_RAY_TRAIN,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
                     "samples_per_launch": units,
                     "timing": "HIP events on the launch stream around each C-ABI call (for mlp_bwd_weights: the "
@@ -412,7 +515,7 @@ def main():
                 entry["frac_of_hbm_peak"] = round(entry["GB/s"] / HBM_PEAK_GBS, 4)
             kernels[k] = entry
         out = {
-            "metric": "rays/sec (64+128 samples, fwd+bwd)", "value": round(n * world * args.steps / dt, 1),
+            "metric": "rays/sec (64+128 samples, fwd+bwd)", "value": round(rays_per_s, 1),
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
@@ -420,16 +523,29 @@ def main():
                                    "NeRF, fwd+bwd+Adam (benchmark configuration: single training step, batch 1024 rays)" % n,
                        "rays_per_gpu": n, "global_rays": n * world, "samples_per_ray": "64+192 evaluations",
                        "parallelism": "dp%d" % world if world > 1 else "single"},
+            "timed_regions": {"repeats": len(leg["regions_ms_per_step"]), "ms_per_step_each": leg["regions_ms_per_step"],
+                              "reported": "median region; each region is exactly --steps steps between barrier + "
+                                          "synchronize, maximum over ranks"},
             "launch_mode": "eager" if args.no_graph else ("eager (%s)" % graph_error) if graph_error else ("hipgraph replay (one graph per step)" if world == 1 else
                                                          "hipgraph replay (3 graphs per step: the all-reduce of the fine network's gradients overlaps the "
                                                          "coarse backward, the coarse half follows, then Adam)"),
             "roofline": roofline, "kernels": kernels,
         }
+        if big is not None:
+            nb = args.big_batch
+            out["train_%d_rays_per_gpu" % nb] = {
+                "workload": "the same training step at %d rays/GPU (the data-parallel configuration's batch)" % nb,
+                "rays_per_s": round(nb * world * args.steps / big["dt"], 1),
+                "ms_per_step": round(big["dt"] / args.steps * 1e3, 4), "ms_per_step_each": big["regions_ms_per_step"],
+                "step_mfma_frac": round(nb * args.steps / big["dt"] * MLP_FLOP_PER_RAY_TRAIN / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                "launch_mode": "eager (%s)" % big["graph_error"] if big["graph_error"] else "as the headline"}
         if allreduce_us is not None:
             out["allreduce"] = {"bytes": int(opt.flat_grad.numel()) * 4, "avg_us": round(allreduce_us, 1),
                                 "note": "summing all-reduce of the whole fp32 gradient bucket of both networks, 10 back to back "
                                         "on rank 0's clock; in a step it is issued as two halves, the first hidden behind the "
                                         "coarse network's backward pass"}
+        if render_sharded is not None:
+            out["render_sharded"] = render_sharded
         if world == 1 and not args.no_render:
             out["render"] = render_section(mc, mf, pe, pv, device, args)
             out["whole_frame_kernels"] = whole_frame_kernels(device)
