@@ -54,28 +54,67 @@ constexpr int gemm_b_nks(int g) { return GEMMS[g].b_nks + GEMMS[g].b2_nks; }
 constexpr int gemm_out_floats(int g) { return gemm_a_nks(g) * 16 * gemm_b_nks(g) * 16 + gemm_a_nks(g) * 16; }
 constexpr int gemm_out_off(int g) { int o = 0; for (int i = 0; i < g; ++i) o += gemm_out_floats(i); return o; }
 constexpr int gemm_stage_kb(int g) { return gemm_a_nks(g) + gemm_b_nks(g); }
-constexpr int TOTAL_STAGE_KB = [] { int s = 0; for (int g = 0; g < NGEMM; ++g) s += gemm_stage_kb(g); return s; }();
 
-constexpr int WGRAD_TARGET_JOBS = 256;     // one workgroup's worth of jobs per CU
+constexpr int WGRAD_TARGET_JOBS = 256;     // one workgroup per CU
+
+// Relative time one workgroup needs per wave tile of each GEMM while every CU is streaming (measured
+// with per-workgroup clock stamps).  The kernel as a whole runs at the HBM rate, but a workgroup's own
+// rate depends on its GEMM's shape (the copies, LDS reads and MFMAs of a step are serial), so equal
+// bytes per workgroup do not end together; the work is divided by this cost instead.
+#ifndef NERF_WG_COST
+#define NERF_WG_COST {67, 131, 131, 131, 131, 146, 131, 131, 127, 24}
+#endif
+constexpr int WGRAD_COST[NGEMM] = NERF_WG_COST;
+constexpr int cost_before(int g) { int c = 0; for (int i = 0; i < g; ++i) c += WGRAD_COST[i]; return c; }
+constexpr int TOTAL_COST = cost_before(NGEMM);
+
+// The whole job -- every GEMM over every wave tile, laid end to end on one line measured in cost --
+// is cut into WGRAD_TARGET_JOBS pieces of equal cost; workgroup p owns piece p.  A piece that crosses
+// the end of a GEMM continues with the first wave tiles of the next one, so a workgroup runs one to
+// three GEMM segments in turn and all workgroups end together whatever the GEMMs' sizes.  Inside
+// GEMM g a piece boundary at cost b falls on wave tile floor((b - start of g) / cost of g).
+__host__ __device__ inline int64_t piece_bound(int64_t n_wt, int p) {
+    return (int64_t)p * n_wt * TOTAL_COST / WGRAD_TARGET_JOBS;
+}
+__host__ __device__ inline int64_t bound_to_wt(int64_t n_wt, int g, int64_t b) {
+    constexpr int cost[NGEMM] = NERF_WG_COST;
+    int before = 0;
+    for (int i = 0; i < g; ++i) before += cost[i];
+    int64_t w = (b - n_wt * before) / cost[g];
+    if (b < n_wt * before) w = 0;
+    return w > n_wt ? n_wt : w;
+}
+// wave tiles [wt0, wt1) of GEMM g that belong to piece p (empty when wt1 <= wt0)
+__host__ __device__ inline void piece_segment(int64_t n_wt, int g, int p, int64_t& wt0, int64_t& wt1) {
+    wt0 = bound_to_wt(n_wt, g, piece_bound(n_wt, p));
+    wt1 = bound_to_wt(n_wt, g, piece_bound(n_wt, p + 1));
+}
 
 struct JobTable {
-    int splits[NGEMM];       // sample-axis splits of each GEMM
-    int job0[NGEMM + 1];     // first job of each GEMM
+    int splits[NGEMM];       // pieces that hold a segment of each GEMM = partial blocks of that GEMM
+    int piece0[NGEMM];       // the first of them; a GEMM's pieces are consecutive
     int64_t part_off[NGEMM]; // float offset of GEMM g's first partial block in the partial buffer
 };
 
 static JobTable make_jobs(int64_t n_wt) {
     JobTable t;
     int64_t off = 0;
-    t.job0[0] = 0;
     for (int g = 0; g < NGEMM; ++g) {
-        int64_t s = ((int64_t)WGRAD_TARGET_JOBS * gemm_stage_kb(g) + TOTAL_STAGE_KB / 2) / TOTAL_STAGE_KB;
-        if (s < 1) s = 1;
-        if (s > n_wt) s = n_wt;
-        t.splits[g] = (int)s;
-        t.job0[g + 1] = t.job0[g] + (int)s;
+        // first and last piece with wave tiles of this GEMM; with very few wave tiles a piece in between
+        // can be empty: it then writes a zero block, so that the GEMM's blocks stay one range
+        int first = -1, last = -1;
+        for (int p = 0; p < WGRAD_TARGET_JOBS; ++p) {
+            int64_t a, b;
+            piece_segment(n_wt, g, p, a, b);
+            if (b > a) {
+                if (first < 0) first = p;
+                last = p;
+            }
+        }
+        t.piece0[g] = first;
+        t.splits[g] = last - first + 1;
         t.part_off[g] = off;
-        off += s * gemm_out_floats(g);
+        off += (int64_t)t.splits[g] * gemm_out_floats(g);
     }
     return t;
 }
@@ -104,6 +143,10 @@ __device__ __forceinline__ typename Prec<PREC>::frag load_unit_frag(const char* 
 template <int PREC>
 __device__ __forceinline__ void store_unit_frag(char* base, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
                                                 int lane_off, const typename Prec<PREC>::frag& f) {
+#ifdef NERF_ABL_STORE_LOCAL      // timing experiment only: every store of a wave goes to one L2-resident KiB
+    *reinterpret_cast<typename Prec<PREC>::frag*>(base + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
+    return;
+#endif
     __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
 }
 
@@ -154,7 +197,11 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
+#ifdef NERF_ABL_LANE_LINEAR      // timing experiment only (wrong layout): lanes store in address order
+    const int lane_off = lane * 16;
+#else
     const int lane_off = c * 32 + h * 16;
+#endif
     const float gscale = a.scale ? *a.scale : 1.0f;
     const int64_t n_wt = a.n_tiles * 8;
     const char* const masks = a.saved + (size_t)n_wt * SAVED_UNITS * 1024;
@@ -269,6 +316,9 @@ struct WgradArgs {
     const char* dz;
     float* partial;
     JobTable jobs;
+#ifdef NERF_WG_STAMP
+    unsigned long long* stamps;      // diagnostic builds: per workgroup {start, end} of s_memrealtime (100 MHz), or null
+#endif
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -337,8 +387,11 @@ __device__ __forceinline__ float frag_sum(const s16x8& f) {
 // One GEMM shape: A_NKS row units x B_NKS column units, computed by a WR x WC grid of waves, each
 // owning TI x TJ tiles of 32 x 32.  Everything about the shape is a compile-time constant so that the
 // per-step body is straight-line code.
-template <int PREC, int A_NKS, int B_NKS, int WR, int WC, int TI, int TJ>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char* lds) {
+// NSUB wave tiles are staged and contracted per step (GEMMs with few units would otherwise keep too few
+// bytes in flight to cover the memory latency).
+template <int PREC, int A_NKS, int B_NKS, int WR, int WC, int TI, int TJ, int NSUB = 1>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char* lds, const int split,
+                                           const int64_t wt0, const int64_t wt1) {
     typedef typename Prec<PREC>::frag frag;
     static_assert(WR * WC <= 8 && WR * TI * 2 >= A_NKS && WC * TJ * 2 == B_NKS, "wave grid must cover the block");
     const int lane = threadIdx.x & 63;
@@ -347,15 +400,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
     const bool active = wave < WR * WC;
     const GemmDesc gd = GEMMS[g];
 
-    const int split = blockIdx.x - a.jobs.job0[g];
-    const int nsplit = a.jobs.splits[g];
-    const int64_t wt0 = a.n_wt * split / nsplit, wt1 = a.n_wt * (split + 1) / nsplit;
-    const int nsteps = (int)(wt1 - wt0);
+    const int ntiles = wt1 > wt0 ? (int)(wt1 - wt0) : 0;
+    const int nsteps = (ntiles + NSUB - 1) / NSUB;
 
-    // staging: unit u of a stage (A units first, then B units) is copied by wave u % 8
+    // staging: a stage holds NSUB wave tiles, each N_UNITS units (A units first, then B units); unit v of
+    // the stage is copied by wave v % 8
     constexpr int N_UNITS = A_NKS + B_NKS;
-    static_assert(N_UNITS * 1024 <= WG_STAGE_BYTES && N_UNITS <= 40, "stage size");
-    const int my_units = (N_UNITS - wave + 7) >> 3;       // 0..5
+    constexpr int STAGE_UNITS = N_UNITS * NSUB;
+    static_assert(STAGE_UNITS * 1024 <= WG_STAGE_BYTES && STAGE_UNITS <= 40, "stage size");
+    const int my_units = (STAGE_UNITS - wave + 7) >> 3;       // 0..5
     // the four operand runs: base of wave tile 0, bytes per wave tile, first unit of the run in the stage
     const int a1n = gd.a_nks, b1n = gd.b_nks;
     const char* a1_src = a.dz + (size_t)dz_ks0(gd.a_layer) * a.n_wt * 1024;
@@ -366,17 +419,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
     const size_t b1_stride = (size_t)SAVED_KS[gd.b_tensor] * 1024, b2_stride = (size_t)SAVED_KS[gd.b2_tensor] * 1024;
 
     auto issue = [&](int step, int stage) {
-        const int64_t wt = wt0 + step;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int u = wave + 8 * i;
-            if (u < N_UNITS) {
+            const int v = wave + 8 * i;
+            if (v < STAGE_UNITS) {
+                const int sub = v / N_UNITS, u = v - sub * N_UNITS;
+                // a wave tile past the end of the range (last step) is copied from the last valid one, so that
+                // every stage is the same number of copies for the counted waits; it is not contracted
+                int64_t wt = wt0 + (int64_t)step * NSUB + sub;
+                if (wt >= wt1) wt = wt1 - 1;
                 const char* src;
                 if (u < a1n) src = a1_src + (size_t)wt * a1_stride + (size_t)u * 1024;
                 else if (u < A_NKS) src = a2_src + (size_t)wt * a2_stride + (size_t)(u - a1n) * 1024;
                 else if (u < A_NKS + b1n) src = b1_src + (size_t)wt * b1_stride + (size_t)(u - A_NKS) * 1024;
                 else src = b2_src + (size_t)wt * b2_stride + (size_t)(u - A_NKS - b1n) * 1024;
-                char* dst = lds + stage * WG_STAGE_BYTES + u * 1024;
+                char* dst = lds + stage * WG_STAGE_BYTES + v * 1024;
                 __builtin_amdgcn_global_load_lds((gbl_char*)src + lane * 16, (lds_char*)dst, 16, 0, WG_DMA_AUX);
             }
         }
@@ -438,44 +495,52 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
         }
         if (active) {
             const uint32_t sb = stage * WG_STAGE_BYTES;
-            TrFrag ta0[TI], tb0[TJ], ta1[TI], tb1[TJ];     // the two 16-sample halves of the stage
 #pragma unroll
-            for (int i = 0; i < TI; ++i) ta0[i] = tr_frag<0>(sb + a_unit[i]);
+            for (int sub = 0; sub < NSUB; ++sub) {
+                if (NSUB > 1 && step * NSUB + sub >= ntiles) break;      // workgroup-uniform
+                constexpr int SUB_BYTES = N_UNITS * 1024;
+                TrFrag ta0[TI], tb0[TJ], ta1[TI], tb1[TJ];     // the two 16-sample halves of the wave tile
+#define NERF_TR(OFF, ADDR) (sub == 0 ? tr_frag<OFF>(ADDR) : sub == 1 ? tr_frag<OFF + (NSUB > 1 ? 1 : 0) * SUB_BYTES>(ADDR) \
+                            : sub == 2 ? tr_frag<OFF + (NSUB > 2 ? 2 : 0) * SUB_BYTES>(ADDR) : tr_frag<OFF + (NSUB > 3 ? 3 : 0) * SUB_BYTES>(ADDR))
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) tb0[j] = tr_frag<0>(sb + b_unit[j]);
+                for (int i = 0; i < TI; ++i) ta0[i] = NERF_TR(0, sb + a_unit[i]);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) ta1[i] = tr_frag<512>(sb + a_unit[i]);
+                for (int j = 0; j < TJ; ++j) tb0[j] = NERF_TR(0, sb + b_unit[j]);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) tb1[j] = tr_frag<512>(sb + b_unit[j]);
-            tr_wait_all<TI, TJ, 0>(ta0, tb0);      // one LDS round trip per stage: both halves were requested above
-            s16x8 af[TI], bf[TJ];
+                for (int i = 0; i < TI; ++i) ta1[i] = NERF_TR(512, sb + a_unit[i]);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = tr_join(ta0[i]);
+                for (int j = 0; j < TJ; ++j) tb1[j] = NERF_TR(512, sb + b_unit[j]);
+#undef NERF_TR
+                tr_wait_all<TI, TJ, 0>(ta0, tb0);      // one LDS round trip per wave tile: both halves were requested above
+                s16x8 af[TI], bf[TJ];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = tr_join(tb0[j]);
-            if (do_bias) {
+                for (int i = 0; i < TI; ++i) af[i] = tr_join(ta0[i]);
 #pragma unroll
-                for (int i = 0; i < TI; ++i) bsum[i] += frag_sum<PREC>(af[i]);
+                for (int j = 0; j < TJ; ++j) bf[j] = tr_join(tb0[j]);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) bsum[i] += frag_sum<PREC>(af[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
+                tr_wait_all<TI, TJ, 0>(ta1, tb1);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[i] = tr_join(ta1[i]);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bf[j] = tr_join(tb1[j]);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) bsum[i] += frag_sum<PREC>(af[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
             }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
-            tr_wait_all<TI, TJ, 0>(ta1, tb1);
-#pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = tr_join(ta1[i]);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = tr_join(tb1[j]);
-            if (do_bias) {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) bsum[i] += frag_sum<PREC>(af[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
         }
         stage = stage + 1 == WG_STAGES ? 0 : stage + 1;
     }
@@ -507,14 +572,32 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
 template <int PREC>
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[WG_LDS_BYTES];
-    int g = 0;
-    while (g + 1 < NGEMM && (int)blockIdx.x >= a.jobs.job0[g + 1]) ++g;
-    // shape dispatch (workgroup-uniform): <A units, B units, wave grid, tiles per wave>
-    if (g == 0) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, g, lds);
-    else if (g == 5) wgrad_body<PREC, 16, 20, 4, 2, 2, 5>(a, g, lds);
-    else if (g == 8) wgrad_body<PREC, 9, 18, 2, 3, 3, 3>(a, g, lds);
-    else if (g == 9) wgrad_body<PREC, 1, 8, 1, 4, 1, 1>(a, g, lds);
-    else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, g, lds);
+#ifdef NERF_WG_STAMP
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int p = blockIdx.x;
+    bool ran = false;
+    for (int g = 0; g < NGEMM; ++g) {
+        const int split = p - a.jobs.piece0[g];
+        if (split < 0 || split >= a.jobs.splits[g]) continue;          // workgroup-uniform
+        int64_t wt0, wt1;
+        piece_segment(a.n_wt, g, p, wt0, wt1);
+        // the previous segment's last LDS reads (other waves) before this one's first copies
+        if (ran) __syncthreads();
+        ran = true;
+        // shape dispatch: <A units, B units, wave grid, tiles per wave, wave tiles per step>
+        if (g == 0) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, g, lds, split, wt0, wt1);
+        else if (g == 5) wgrad_body<PREC, 16, 20, 4, 2, 2, 5>(a, g, lds, split, wt0, wt1);
+        else if (g == 8) wgrad_body<PREC, 9, 18, 2, 3, 3, 3>(a, g, lds, split, wt0, wt1);
+        else if (g == 9) wgrad_body<PREC, 1, 8, 1, 4, 1, 1, 4>(a, g, lds, split, wt0, wt1);
+        else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, g, lds, split, wt0, wt1);
+    }
+#ifdef NERF_WG_STAMP
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[2 * blockIdx.x] = t_start | ((unsigned long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 56);   // XCC id on top
+        a.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,7 +794,13 @@ extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* packed, const void* s
 
     WgradArgs w{};
     w.n_wt = n_wt; w.saved = (const char*)saved; w.dz = (const char*)dz; w.partial = (float*)partial; w.jobs = jobs;
-    const dim3 gw((unsigned)jobs.job0[NGEMM]), tw(512);
+#ifdef NERF_WG_STAMP
+    {   // stamps go behind everything the library uses of the partial buffer, when the caller left room
+        const int64_t used = prod_off + (int64_t)PROD_FLOATS * 4;
+        w.stamps = partial_bytes >= used + 16 * 1024 ? reinterpret_cast<unsigned long long*>((char*)partial + used) : nullptr;
+    }
+#endif
+    const dim3 gw((unsigned)WGRAD_TARGET_JOBS), tw(512);
     if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_BF16>, gw, tw, 0, st, w);
     else hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_FP16>, gw, tw, 0, st, w);
     rc = nerf_launch_status();

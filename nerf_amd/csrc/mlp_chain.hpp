@@ -2,9 +2,9 @@
 // See mlp_common.hpp for the data layout.
 //
 // A workgroup is 8 waves (2 per SIMD, <= 256 VGPRs each); a wave owns 32 samples for a whole
-// pass over the network.  Weights arrive as a stream of 1 KiB A-fragment blocks through a
-// 3-slot LDS ring of 32 KiB chunks filled by LDS-DMA (global_load_lds_dwordx4): while chunk c
-// is consumed, chunks c+1 and c+2 are in flight or landed.  The only workgroup barrier is at
+// pass over the network.  Weights arrive as a stream of 1 KiB A-fragment blocks through an
+// LDS ring of RING_SLOTS (3 or 4) 32 KiB chunks filled by LDS-DMA (global_load_lds_dwordx4): while chunk c
+// is consumed, the following RING_SLOTS - 1 chunks are in flight or landed.  The only workgroup barrier is at
 // chunk entry, paired with a COUNTED vmcnt wait that leaves the newest chunk's DMA in flight.
 #pragma once
 #include "mlp_common.hpp"
@@ -56,9 +56,9 @@ __device__ __forceinline__ void ring_init(Ring& r, char* lds, const void* stream
     r.extra_enters = 0;
     r.rd_base = LDS_RING_OFF;
     r.stream_bytes = n_chunks * CHUNK_BYTES;
-    ring_issue(r, lds, r.wave_off, 0);
-    ring_issue(r, lds, r.wave_off + CHUNK_BYTES, 1);
-    r.src_off = r.wave_off + 2 * CHUNK_BYTES;
+#pragma unroll
+    for (int c = 0; c < RING_SLOTS - 1; ++c) ring_issue(r, lds, r.wave_off + c * CHUNK_BYTES, c);
+    r.src_off = r.wave_off + (RING_SLOTS - 1) * CHUNK_BYTES;
 }
 
 // Entry into the next chunk of the stream.  On return the chunk is readable at rd_base.
@@ -74,18 +74,20 @@ __device__ __forceinline__ void ring_init(Ring& r, char* lds, const void* stream
 //    chunk waited for and may stay in flight; from the third entry on it is older and has landed.
 template <int YOUNGER = 0, int SIDE = 0>
 __device__ __forceinline__ void ring_enter(Ring& r, char* lds) {
-    static_assert(DMA_PER_CHUNK + YOUNGER + SIDE <= 63, "vmcnt is a 6-bit counter");
+    // chunks requested after the one entered now: RING_SLOTS - 2 of them
+    constexpr int DMA_YOUNGER = (RING_SLOTS - 2) * DMA_PER_CHUNK;
+    static_assert(DMA_YOUNGER + YOUNGER + SIDE <= 63, "vmcnt is a 6-bit counter");
     if (SIDE > 0 && r.extra_enters > 0) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK + YOUNGER + SIDE) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_YOUNGER + YOUNGER + SIDE) : "memory");
         --r.extra_enters;
     } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_CHUNK + YOUNGER) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_YOUNGER + YOUNGER) : "memory");
     }
 #ifndef NERF_ABL_NO_BARRIER          // timing experiment only: results are wrong without the barrier
     __builtin_amdgcn_s_barrier();
 #endif
     r.slot = r.slot == RING_SLOTS - 1 ? 0 : r.slot + 1;
-    int refill = r.slot + 2;
+    int refill = r.slot + RING_SLOTS - 1;
     if (refill >= RING_SLOTS) refill -= RING_SLOTS;
     // the offset repeats with the pass; keep it opaque so that it stays one scalar register
     // instead of a hoisted table of per-chunk addresses
@@ -159,13 +161,14 @@ constexpr int pf_lo(int B0, int NB, int i) {
     return pf_hi(B0, NB, i - 1) + 1;
 }
 
-// Tile epilogues of this layer that ran during the two chunks before block i.  The chunk entered at
-// block i was requested two entries earlier, so everything issued during those two chunks -- one chunk of
-// ring DMA and the stores of these epilogues -- is younger than it and may stay in flight; a store then
-// has two chunk times, not one, to be acknowledged before it would hold up a chunk entry.
+// Tile epilogues of this layer that ran during the RING_SLOTS - 1 chunks before block i.  The chunk entered
+// at block i was requested that many entries earlier, so everything issued since -- the younger chunks of
+// ring DMA and the stores of these epilogues -- may stay in flight; a store then has RING_SLOTS - 1 chunk
+// times to be acknowledged before it would hold up a chunk entry.
 constexpr int tiles_ended_before(int NT, int NK, int i) {
     int n = 0;
-    for (int j = (i > 2 * CHUNK_BLOCKS ? i - 2 * CHUNK_BLOCKS : 0); j < i; ++j) n += (stream_ks(NT, NK, j) == NK - 1);
+    constexpr int WINDOW = (RING_SLOTS - 1) * CHUNK_BLOCKS;
+    for (int j = (i > WINDOW ? i - WINDOW : 0); j < i; ++j) n += (stream_ks(NT, NK, j) == NK - 1);
     return n;
 }
 

@@ -50,7 +50,15 @@ constexpr int WAVE_SAMPLES = 32;
 constexpr int BLOCK_BYTES = 1024;
 constexpr int CHUNK_BLOCKS = 32;
 constexpr int CHUNK_BYTES = CHUNK_BLOCKS * BLOCK_BYTES;
-constexpr int RING_SLOTS = 3;
+// slots of the LDS weight ring: one being read, the others in flight or landed.  A translation unit may ask
+// for more than three (NERF_RING_SLOTS before the include) where its LDS budget allows: a chunk is then
+// requested further ahead, which gives the wave's older stores longer to complete before a chunk entry has
+// to wait for them (the memory counter is in order).
+#ifndef NERF_RING_SLOTS
+#define NERF_RING_SLOTS 3
+#endif
+constexpr int RING_SLOTS = NERF_RING_SLOTS;
+static_assert(RING_SLOTS >= 3, "ring");
 
 // ---- flat parameter offsets (state_dict order) ------------------------------------------
 constexpr int OFF_W0 = 0;                       constexpr int OFF_B0 = OFF_W0 + 256 * 63;

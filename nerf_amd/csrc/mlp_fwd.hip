@@ -108,6 +108,10 @@ __global__ __launch_bounds__(256) void encode_units_kernel(int64_t M, int64_t n_
 template <int PREC>
 __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
                                           int lane_off, const typename Prec<PREC>::frag& f) {
+#ifdef NERF_ABL_STORE_LOCAL      // timing experiment only: every store of a wave goes to one L2-resident KiB
+    *reinterpret_cast<typename Prec<PREC>::frag*>(saved + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
+    return;
+#endif
     __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
 }
 
@@ -135,7 +139,11 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
+#ifdef NERF_ABL_LANE_LINEAR      // timing experiment only (wrong layout): lanes store in address order
+    const int lane_off = lane * 16;
+#else
     const int lane_off = c * 32 + h * 16;        // byte offset of this lane's fragment in a saved unit
+#endif
 
     {   // bias table -> LDS (plain loads, before any LDS-DMA is in flight)
         const float* bg = reinterpret_cast<const float*>(a.packed + PACK_BIAS_OFF);
