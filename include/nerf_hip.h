@@ -186,6 +186,39 @@ int64_t nerf_mlp_encoded_workspace_bytes(int64_t n_samples);
 int nerf_mlp_fwd_encoded(int64_t M, const float *x_pts, const float *x_views, const void *packed,
                          int precision, float *raw, void *saved, void *workspace, void *stream);
 
+/* ------------------------------------------------------------------------
+ * fp32-operand forward of NeRF.forward -- src/nerf_project/models/nerf.py:173-209 for any
+ * architecture its constructor (:100-153) accepts within the limits below: the validation mode
+ * (v_mfma_f32_32x32x2_f32, exact fp32 products and sums).  The network is handed over as a list of
+ * layers.  A layer multiplies one or two input segments (skip connection, nerf.py:184: [encoded
+ * points, hidden]; colour head, :198: [feature, encoded view direction]) and writes either one of the
+ * two hidden buffers or columns dst_col .. of raw [M,4] (nerf.py:209).  x_pts [M,cp], x_views [M,cv]
+ * (NULL when cv = 0) are the encoded inputs of nerf.py:155.
+ */
+#define NERF_FP32_MAX_WIDTH 256  /* widest hidden layer */
+#define NERF_FP32_MAX_PTS 64     /* encoded point features, padded */
+#define NERF_FP32_MAX_VIEWS 32   /* encoded view-direction features, padded */
+#define NERF_FP32_MAX_LAYERS 16
+enum { NERF_FP32_BUF_PTS = 0, NERF_FP32_BUF_VIEWS = 1, NERF_FP32_BUF_A = 2, NERF_FP32_BUF_B = 3, NERF_FP32_DST_RAW = 4 };
+typedef struct {
+    const float *weights[2]; /* per segment: nerf_mlp_fp32_pack_segment output (device) */
+    int k_padded[2];         /* per segment: input features rounded up to a multiple of 8 */
+    int src[2];              /* per segment: NERF_FP32_BUF_* the inputs are read from */
+    int n_segments;          /* 1 or 2 */
+    const float *bias;       /* [out_features] (device) */
+    int out_features;
+    int relu;                /* 1: max(., 0) */
+    int dst;                 /* NERF_FP32_BUF_A / _B, or NERF_FP32_DST_RAW */
+    int dst_col;             /* first column of raw when dst is NERF_FP32_DST_RAW */
+} nerf_fp32_layer_t;
+/* floats of one packed segment of a [rows, cols] weight block */
+int64_t nerf_mlp_fp32_segment_floats(int rows, int cols);
+/* w: row-major [rows, ld]; columns col0 .. col0+cols-1 are rewritten in MFMA fragment order, zero padded */
+int nerf_mlp_fp32_pack_segment(const float *w, int rows, int ld, int col0, int cols, float *dst, void *stream);
+/* layers: HOST array of n_layers descriptors (copied into the launch) */
+int nerf_mlp_fp32_fwd(int64_t M, const float *x_pts, int cp, const float *x_views, int cv,
+                      const nerf_fp32_layer_t *layers, int n_layers, float *raw, void *stream);
+
 /* The same forward as nerf_mlp_fwd_encoded(saved = NULL) with the workspace inside the library.  It has no
  * counterpart in the reference: it exists for callers that cannot allocate device memory -- code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The call allocates nothing

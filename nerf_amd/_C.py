@@ -48,6 +48,9 @@ _SIGS = {
     "nerf_mlp_partial_bytes": (c_int64, [c_int64]),
     "nerf_mlp_bwd_data": (c_int, [c_int64, P, P, c_int, P, P, P, P]),
     "nerf_mlp_bwd_weights": (c_int, [c_int64, P, P, P, c_int, P, P, c_int64, P, P]),
+    "nerf_mlp_fp32_segment_floats": (c_int64, [c_int, c_int]),
+    "nerf_mlp_fp32_pack_segment": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "nerf_mlp_fp32_fwd": (c_int, [c_int64, P, c_int, P, c_int, P, c_int, P, P]),
     "nerf_adam_step_dev": (c_int, [c_int64, P, P, P, P, P, P]),
     "nerf_mse_pair": (c_int, [c_int64, P, P, P, P, P, P, P]),
     "nerf_adam_step": (c_int, [c_int64, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
@@ -58,6 +61,16 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.argtypes = _args
 
 SYMBOLS = tuple(_SIGS)
+
+
+class Fp32Layer(ctypes.Structure):
+    """nerf_fp32_layer_t of include/nerf_hip.h: one layer of the fp32 forward's program."""
+    _fields_ = [("weights", c_void_p * 2), ("k_padded", c_int * 2), ("src", c_int * 2), ("n_segments", c_int),
+                ("bias", c_void_p), ("out_features", c_int), ("relu", c_int), ("dst", c_int), ("dst_col", c_int)]
+
+
+FP32_MAX_WIDTH, FP32_MAX_PTS, FP32_MAX_VIEWS, FP32_MAX_LAYERS = 256, 64, 32, 16
+FP32_BUF_PTS, FP32_BUF_VIEWS, FP32_BUF_A, FP32_BUF_B, FP32_DST_RAW = 0, 1, 2, 3, 4
 NERF_MLP_NPARAMS = 595844
 PREC = {"bf16": 0, "fp16": 1}
 

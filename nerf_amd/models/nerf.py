@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _C, ops
 
 _PRECISIONS = ("bf16", "fp16", "fp32")
 _FUSED_PRECISIONS = ("bf16", "fp16")
@@ -96,6 +96,7 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(W, 4)
         self._pack_key = None
         self._packed = None
+        self._fp32_prog = None
 
     # -- kernel plumbing ------------------------------------------------------------------
     def kernel_supported(self) -> bool:
@@ -173,18 +174,127 @@ class NeRF(nn.Module):
                                      self.ordered_params())
 
 
+    # -- fp32 validation mode -----------------------------------------------------------------
+    def fp32_kernel_supported(self) -> bool:
+        """True when the fp32 MFMA kernel covers this architecture (its LDS-resident activations bound the
+        widths; a skip connection after the last hidden layer is not a network the reference can run)."""
+        n_layers = self.D + (4 if self.use_viewdirs else 1)
+        return (1 <= self.W <= _C.FP32_MAX_WIDTH and 1 <= self.input_ch_pts <= _C.FP32_MAX_PTS
+                and (not self.use_viewdirs or 1 <= self.input_ch_views <= _C.FP32_MAX_VIEWS)
+                and n_layers <= _C.FP32_MAX_LAYERS and all(0 <= i < self.D - 1 for i in self.skips))
+
+    def _fp32_program(self):
+        """The layer list of the fp32 kernel for the current weights: (ctypes array, tensors it points to).
+        Cached under no_grad like the 16-bit weight streams; rebuilt on every call while training."""
+        ps = self.ordered_params()
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        key = None if training else ("fp32",) + tuple((p.data_ptr(), p._version) for p in ps)
+        if not training and key == self._pack_key and self._fp32_prog is not None:
+            return self._fp32_prog
+        keep, layers = [], []
+        pad8 = lambda v: (v + 7) // 8 * 8
+
+        def add(lin, segments, relu, dst, dst_col=0):
+            L = _C.Fp32Layer()
+            L.n_segments = len(segments)
+            for s, (col0, cols, src) in enumerate(segments):
+                w = ops.fp32_pack_segment(lin.weight, col0, cols)
+                keep.append(w)
+                L.weights[s], L.k_padded[s], L.src[s] = w.data_ptr(), pad8(cols), src
+            b = lin.bias.detach().contiguous()
+            keep.append(b)
+            L.bias, L.out_features, L.relu, L.dst, L.dst_col = b.data_ptr(), lin.out_features, int(relu), dst, dst_col
+            layers.append(L)
+
+        with torch.no_grad():
+            Cp, Cv, W = self.input_ch_pts, self.input_ch_views, self.W
+            cur, other = _C.FP32_BUF_PTS, _C.FP32_BUF_A
+            for i, lin in enumerate(self.pts_linears):
+                if i > 0 and (i - 1) in self.skips:          # input is [encoded points, hidden] (nerf.py:184)
+                    segs = [(0, Cp, _C.FP32_BUF_PTS), (Cp, W, cur)]
+                else:
+                    segs = [(0, lin.in_features, cur)]
+                add(lin, segs, True, other)
+                cur, other = other, (_C.FP32_BUF_B if other == _C.FP32_BUF_A else _C.FP32_BUF_A)
+            if self.use_viewdirs:
+                add(self.sigma_linear, [(0, W, cur)], False, _C.FP32_DST_RAW, 3)
+                add(self.feature_linear, [(0, W, cur)], False, other)
+                add(self.rgb_layers[0], [(0, W, other), (W, Cv, _C.FP32_BUF_VIEWS)], True, cur)
+                add(self.rgb_layers[2], [(0, W // 2, cur)], False, _C.FP32_DST_RAW, 0)
+            else:
+                add(self.output_linear, [(0, W, cur)], False, _C.FP32_DST_RAW, 0)
+        arr = (_C.Fp32Layer * len(layers))(*layers)
+        self._fp32_prog = (arr, keep)
+        if not training:
+            self._pack_key = key
+        return self._fp32_prog
+
     def _forward_fp32(self, x_pts_encoded: torch.Tensor, x_views_encoded: Optional[torch.Tensor]) -> torch.Tensor:
-        """Layer-by-layer fp32 evaluation of nerf.py:173-209 (validation mode, any architecture)."""
+        """fp32 evaluation of nerf.py:173-209 (validation mode, any architecture): the fp32 MFMA kernel
+        where it covers the architecture, else layer-by-layer library GEMMs."""
+        if x_pts_encoded.shape[-1] != self.input_ch_pts:
+            raise ValueError(f"expected encoded points of width {self.input_ch_pts}, got {x_pts_encoded.shape[-1]}")
+        if not self.use_viewdirs:
+            x_views_encoded = None
+        elif x_views_encoded.shape[-1] != self.input_ch_views:
+            raise ValueError(f"expected encoded view directions of width {self.input_ch_views}, got {x_views_encoded.shape[-1]}")
+        if not self.fp32_kernel_supported():
+            return self._forward_library(x_pts_encoded, x_views_encoded, None)
+        lead = x_pts_encoded.shape[:-1]
+        xp = x_pts_encoded.reshape(-1, self.input_ch_pts)
+        xv = None if x_views_encoded is None else x_views_encoded.reshape(-1, self.input_ch_views)
+        raw = _Fp32Forward.apply(self, xp, xv, *self.ordered_params())
+        return raw.view(*lead, 4)
+
+    def _forward_library(self, x_pts_encoded, x_views_encoded, params) -> torch.Tensor:
+        """nerf.py:173-209 layer by layer with ``torch.nn.functional.linear`` (rocBLAS), on ``params`` (a list in
+        state_dict order) or on the module's own parameters."""
+        F = torch.nn.functional
+        it = iter(self.ordered_params() if params is None else params)
+        lin = lambda x: F.linear(x, next(it), next(it))
         h = x_pts_encoded
-        for i, layer in enumerate(self.pts_linears):
-            h = torch.relu(layer(h))
+        for i in range(self.D):
+            h = torch.relu(lin(h))
             if i in self.skips:
                 h = torch.cat((x_pts_encoded, h), dim=-1)
         if not self.use_viewdirs:
-            return self.output_linear(h)
-        sigma = self.sigma_linear(h)
-        rgb = self.rgb_layers(torch.cat((self.feature_linear(h), x_views_encoded), dim=-1))
+            return lin(h)
+        sigma = lin(h)
+        feat = lin(h)
+        g = torch.relu(lin(torch.cat((feat, x_views_encoded), dim=-1)))
+        rgb = lin(g)
         return torch.cat((rgb, sigma), dim=-1)
+
+
+class _Fp32Forward(torch.autograd.Function):
+    """Forward: the fp32 MFMA kernel.  Backward: the layers are evaluated again with library GEMMs under
+    autograd and differentiated there (the validation mode's gradients are fp32 library arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, model, x_pts, x_views, *params):
+        layers, _keep = model._fp32_program()
+        raw = ops.fp32_mlp_forward(x_pts, x_views, layers)
+        ctx.model = model
+        ctx.has_views = x_views is not None
+        ctx.save_for_backward(x_pts, *([x_views] if x_views is not None else []), *params)
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        saved = ctx.saved_tensors
+        x_pts = saved[0]
+        x_views = saved[1] if ctx.has_views else None
+        params = saved[2 if ctx.has_views else 1:]
+        need = list(ctx.needs_input_grad[1:])          # x_pts, x_views, params...
+        with torch.enable_grad():
+            xp = x_pts.detach().requires_grad_(need[0])
+            xv = None if x_views is None else x_views.detach().requires_grad_(need[1])
+            ps = [p.detach().requires_grad_(n) for p, n in zip(params, need[2:])]
+            raw = ctx.model._forward_library(xp, xv, ps)
+            wanted = [t for t, n in zip([xp, xv] + ps, need) if n and t is not None]
+            got = iter(torch.autograd.grad(raw, wanted, d_raw.contiguous(), allow_unused=True)) if wanted else iter(())
+        out = [next(got) if (n and t is not None) else None for t, n in zip([xp, xv] + ps, need)]
+        return (None, *out)
 
 
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, N_samples: int, det: bool = False, *,

@@ -460,6 +460,39 @@ def fused_mlp_encoded(x_pts, x_views, precision: str, packed: torch.Tensor, para
 
 
 # ---------------------------------------------------------------------------
+# fp32-operand MLP forward (validation mode, any architecture within the kernel's limits)
+# ---------------------------------------------------------------------------
+
+def fp32_pack_segment(weight: torch.Tensor, col0: int, cols: int) -> torch.Tensor:
+    """Columns [col0, col0+cols) of a [rows, ld] weight matrix in the fragment order of the fp32 kernel."""
+    w = _gpu_f32(weight.detach(), "weight")
+    rows, ld = w.shape
+    out = torch.empty((int(lib.nerf_mlp_fp32_segment_floats(rows, cols)),), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        check(lib.nerf_mlp_fp32_pack_segment(_p(w), rows, ld, int(col0), int(cols), _p(out), _stream(w.device)),
+              "nerf_mlp_fp32_pack_segment")
+    return out
+
+
+def fp32_mlp_forward(x_pts: torch.Tensor, x_views: Optional[torch.Tensor], layers) -> torch.Tensor:
+    """raw [M, 4] of the network described by ``layers`` (a ctypes array of ``_C.Fp32Layer``; the tensors its
+    pointers refer to must be kept alive by the caller) on encoded inputs [M, cp] and [M, cv] or None."""
+    xp = _gpu_f32(x_pts, "x_pts_encoded")
+    M, cp = xp.shape
+    xv, cv = None, 0
+    if x_views is not None:
+        xv = _gpu_f32(x_views, "x_views_encoded")
+        if xv.shape[0] != M:
+            raise ValueError("x_pts_encoded and x_views_encoded must have the same number of rows")
+        cv = xv.shape[1]
+    raw = torch.empty((M, 4), dtype=torch.float32, device=xp.device)
+    with torch.cuda.device(xp.device), _timed("mlp_fwd_fp32", xp.device, M):
+        check(lib.nerf_mlp_fp32_fwd(M, _p(xp), cp, _p(xv), cv, ctypes.cast(layers, ctypes.c_void_p), len(layers), _p(raw),
+                                    _stream(xp.device)), "nerf_mlp_fp32_fwd")
+    return raw
+
+
+# ---------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------
 

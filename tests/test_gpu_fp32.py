@@ -78,3 +78,54 @@ def test_fp32_train_step_golden(amd, golden):
         assert rel(m.sigma_linear.weight.grad, T(g[f"g_{tag}_sigma_w"])) < 2e-3
         assert rel(m.rgb_layers[2].weight.grad, T(g[f"g_{tag}_rgb2_w"])) < 2e-3
         assert rel(m.pts_linears[0].bias.grad, T(g[f"g_{tag}_l0_b"])) < 2e-3
+
+
+@pytest.mark.parametrize("arch", [
+    dict(),                                                        # the scripts' network
+    dict(D=4, W=64, skips=[2]),                                    # reference tests/test_nerf_model.py:105-109
+    dict(use_viewdirs=False),                                      # the script default (train_nerf.py:79)
+    dict(D=3, W=100, skips=[0], input_ch_pts=27, input_ch_views=15),   # widths that need padding
+    dict(D=12, W=32, skips=[1, 5, 9]),                             # several skips, the deepest program (16 layers)
+])
+def test_fp32_kernel_runs_every_architecture(amd, arch):
+    """The fp32 MFMA kernel is what evaluates the validation mode (not a library GEMM), for ragged sizes too,
+    and agrees with layer-by-layer fp32 GEMMs to summation order (2e-5 abs on raw of order 0.1)."""
+    from nerf_amd import ops
+    torch.manual_seed(7)
+    m = amd.NeRF(precision="fp32", **arch).to(DEV)
+    assert m.fp32_kernel_supported() and not m.fused()
+    for M in (1, 63, 1000):
+        xp = torch.randn(M, m.input_ch_pts, device=DEV)
+        xv = torch.randn(M, m.input_ch_views, device=DEV) if m.use_viewdirs else None
+        ops.KERNEL_TIMES = {}
+        with torch.no_grad():
+            raw = m(xp, xv) if xv is not None else m(xp)
+            times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+            ref = m._forward_library(xp, xv, None)
+        assert "mlp_fwd_fp32" in times
+        assert raw.shape == (M, 4) and maxabs(raw, ref) < 2e-5
+    # leading dimensions are kept; gradients come out as the library's
+    xp = torch.randn(5, 7, m.input_ch_pts, device=DEV)
+    xv = torch.randn(5, 7, m.input_ch_views, device=DEV) if m.use_viewdirs else None
+    cot = torch.randn(5, 7, 4, device=DEV)
+    out = m(xp, xv) if xv is not None else m(xp)
+    assert out.shape == (5, 7, 4)
+    g_kernel = torch.autograd.grad(out, list(m.parameters()), cot)
+    g_lib = torch.autograd.grad(m._forward_library(xp, xv, None), list(m.parameters()), cot)
+    for a, b in zip(g_kernel, g_lib):
+        assert maxabs(a, b) <= 1e-6 * (1 + b.abs().max().item())
+    # weights changed in place under no_grad: the cached program follows
+    with torch.no_grad():
+        before = m(xp, xv) if xv is not None else m(xp)
+        for p in m.parameters():
+            p.mul_(0.5)
+        after = m(xp, xv) if xv is not None else m(xp)
+        assert maxabs(after, m._forward_library(xp, xv, None)) < 2e-5 and maxabs(after, before) > 1e-4
+
+
+def test_fp32_kernel_limits_fall_back(amd):
+    """Beyond the kernel's widths the validation mode still runs (library GEMMs) and says so."""
+    m = amd.NeRF(D=2, W=320, skips=[], precision="fp32").to(DEV)
+    assert not m.fp32_kernel_supported()
+    with torch.no_grad():
+        assert m(torch.randn(10, 63, device=DEV), torch.randn(10, 27, device=DEV)).shape == (10, 4)
