@@ -154,6 +154,13 @@ int nerf_mse_pair(int64_t n_elements, const float *a, const float *b, const floa
  * the MFMA fragment streams the kernels read.
  */
 #define NERF_MLP_NPARAMS 595844
+/* The network without view directions (NeRF(use_viewdirs=False), models/nerf.py:151-153, :202-206, the
+ * default of scripts/train_nerf.py:79): pts_linears.0 .. 7 then output_linear [4,256]; 494 084 floats.
+ * Every MLP entry point takes it when NERF_ARCH_NOVIEW is or-ed into its `precision` argument (and
+ * NERF_PACK_NOVIEW into nerf_mlp_pack's `streams`); buffer sizes are the same as for the full network,
+ * d_params has NERF_MLP_NPARAMS_NOVIEW entries, and x_views may be NULL. */
+#define NERF_MLP_NPARAMS_NOVIEW 494084
+#define NERF_ARCH_NOVIEW 0x100
 
 /* bytes of the packed-weight buffer (forward + transposed streams + biases) */
 int64_t nerf_mlp_packed_bytes(void);
@@ -161,7 +168,7 @@ int64_t nerf_mlp_packed_bytes(void);
 /* params: flat fp32 [NERF_MLP_NPARAMS]; packed: nerf_mlp_packed_bytes() bytes, 256-byte aligned.
  * streams: which weight streams to (re)write -- NERF_PACK_TRAIN for nerf_mlp_fwd with `saved`,
  * nerf_mlp_fwd_encoded and the backward, NERF_PACK_INFER for nerf_mlp_fwd without `saved`, or both. */
-enum { NERF_PACK_TRAIN = 1, NERF_PACK_INFER = 2 };
+enum { NERF_PACK_TRAIN = 1, NERF_PACK_INFER = 2, NERF_PACK_NOVIEW = 4 /* params describe the network without view directions */ };
 int nerf_mlp_pack(const float *params, int precision, int streams, void *packed, void *stream);
 
 /* bytes of activations the training forward saves per sample (for nerf_mlp_bwd) */

@@ -72,6 +72,8 @@ class Fp32Layer(ctypes.Structure):
 FP32_MAX_WIDTH, FP32_MAX_PTS, FP32_MAX_VIEWS, FP32_MAX_LAYERS = 256, 64, 32, 16
 FP32_BUF_PTS, FP32_BUF_VIEWS, FP32_BUF_A, FP32_BUF_B, FP32_DST_RAW = 0, 1, 2, 3, 4
 NERF_MLP_NPARAMS = 595844
+NERF_MLP_NPARAMS_NOVIEW = 494084
+ARCH_NOVIEW = 0x100          # or-ed into the precision argument: the network without view directions
 PREC = {"bf16": 0, "fp16": 1}
 
 

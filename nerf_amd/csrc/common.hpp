@@ -16,6 +16,12 @@ static inline int nerf_launch_status() {
     return e == hipSuccess ? NERF_OK : (int)e;
 }
 
+// `precision` of the MLP entry points: the operand type, optionally with the architecture flag
+static inline bool nerf_prec_ok(int precision) {
+    const int p = precision & ~NERF_ARCH_NOVIEW;
+    return p == NERF_PREC_BF16 || p == NERF_PREC_FP16;
+}
+
 static inline bool nerf_aligned(const void* p, uintptr_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
 
 namespace nerf {

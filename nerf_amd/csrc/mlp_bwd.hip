@@ -33,8 +33,23 @@ struct GemmDesc {
     int b_tensor, b_nks;            // cols: saved tensor b_tensor ...
     int b2_tensor, b2_nks;          // ... then b2_tensor (b2_nks = 0: none)
 };
-constexpr int NGEMM = 10;
-constexpr GemmDesc GEMMS[NGEMM] = {
+constexpr int NGEMM = 10;          // most GEMMs of an architecture
+struct ArchTab {
+    int ngemm;
+    GemmDesc g[NGEMM];
+    int cost[NGEMM];      // relative time per wave tile, see WGRAD_COST below
+};
+// Relative time one workgroup needs per wave tile of each GEMM while every CU is streaming (measured
+// with per-workgroup clock stamps).  The kernel as a whole runs at the HBM rate, but a workgroup's own
+// rate depends on its GEMM's shape (the copies, LDS reads and MFMAs of a step are serial), so equal
+// bytes per workgroup do not end together; the work is divided by this cost instead.
+#ifndef NERF_WG_COST
+#define NERF_WG_COST {67, 131, 131, 131, 131, 146, 131, 131, 127, 24}
+#endif
+#ifndef NERF_WG_COST_NV
+#define NERF_WG_COST_NV {67, 131, 131, 131, 131, 146, 131, 131, 50, 0}
+#endif
+constexpr ArchTab TAB_VIEW = {10, {
     {0, 16, 0, 0, SV_PE, 4, 0, 0},                  // 0: pts_linears.0
     {1, 16, 0, 0, SV_H0 + 0, 16, 0, 0},             // 1: pts_linears.1
     {2, 16, 0, 0, SV_H0 + 1, 16, 0, 0},             // 2
@@ -47,47 +62,47 @@ constexpr GemmDesc GEMMS[NGEMM] = {
     //    rgb_layers.0[:, :256], factored), sigma_linear (row 128), rgb_layers.0[:, 256:]
     {9, 8, 8, 1, SV_H0 + 7, 16, SV_VPE, 2},
     {10, 1, 0, 0, SV_G, 8, 0, 0},                   // 9: rgb_layers.2 (rows 0..2)
-};
-constexpr int gemm_a_nks(int g) { return GEMMS[g].a_nks + GEMMS[g].a2_nks; }
-constexpr int gemm_b_nks(int g) { return GEMMS[g].b_nks + GEMMS[g].b2_nks; }
+}, NERF_WG_COST};
+// the network without view directions: GEMMs 0..7 as above, then output_linear (rows 0..3 of dZ_o, kept
+// where the full network keeps dZ10) x H7
+constexpr ArchTab TAB_NOVIEW = {9, {
+    {0, 16, 0, 0, SV_PE, 4, 0, 0}, {1, 16, 0, 0, SV_H0 + 0, 16, 0, 0}, {2, 16, 0, 0, SV_H0 + 1, 16, 0, 0},
+    {3, 16, 0, 0, SV_H0 + 2, 16, 0, 0}, {4, 16, 0, 0, SV_H0 + 3, 16, 0, 0}, {5, 16, 0, 0, SV_H0 + 4, 16, SV_PE, 4},
+    {6, 16, 0, 0, SV_H0 + 5, 16, 0, 0}, {7, 16, 0, 0, SV_H0 + 6, 16, 0, 0},
+    {10, 1, 0, 0, SV_H0 + 7, 16, 0, 0},             // 8: output_linear
+    {0, 0, 0, 0, 0, 0, 0, 0},
+}, NERF_WG_COST_NV};
+template <bool VIEW> __host__ __device__ constexpr const ArchTab& arch_tab() { return VIEW ? TAB_VIEW : TAB_NOVIEW; }
+
+__host__ __device__ constexpr int gemm_a_nks(const ArchTab& t, int g) { return t.g[g].a_nks + t.g[g].a2_nks; }
+__host__ __device__ constexpr int gemm_b_nks(const ArchTab& t, int g) { return t.g[g].b_nks + t.g[g].b2_nks; }
 // partial block of GEMM g: [rows][cols] floats, then one bias sum per row
-constexpr int gemm_out_floats(int g) { return gemm_a_nks(g) * 16 * gemm_b_nks(g) * 16 + gemm_a_nks(g) * 16; }
-constexpr int gemm_out_off(int g) { int o = 0; for (int i = 0; i < g; ++i) o += gemm_out_floats(i); return o; }
-constexpr int gemm_stage_kb(int g) { return gemm_a_nks(g) + gemm_b_nks(g); }
+__host__ __device__ constexpr int gemm_out_floats(const ArchTab& t, int g) {
+    return gemm_a_nks(t, g) * 16 * gemm_b_nks(t, g) * 16 + gemm_a_nks(t, g) * 16;
+}
+__host__ __device__ constexpr int total_cost(const ArchTab& t) { int c = 0; for (int g = 0; g < t.ngemm; ++g) c += t.cost[g]; return c; }
 
 constexpr int WGRAD_TARGET_JOBS = 256;     // one workgroup per CU
-
-// Relative time one workgroup needs per wave tile of each GEMM while every CU is streaming (measured
-// with per-workgroup clock stamps).  The kernel as a whole runs at the HBM rate, but a workgroup's own
-// rate depends on its GEMM's shape (the copies, LDS reads and MFMAs of a step are serial), so equal
-// bytes per workgroup do not end together; the work is divided by this cost instead.
-#ifndef NERF_WG_COST
-#define NERF_WG_COST {67, 131, 131, 131, 131, 146, 131, 131, 127, 24}
-#endif
-constexpr int WGRAD_COST[NGEMM] = NERF_WG_COST;
-constexpr int cost_before(int g) { int c = 0; for (int i = 0; i < g; ++i) c += WGRAD_COST[i]; return c; }
-constexpr int TOTAL_COST = cost_before(NGEMM);
 
 // The whole job -- every GEMM over every wave tile, laid end to end on one line measured in cost --
 // is cut into WGRAD_TARGET_JOBS pieces of equal cost; workgroup p owns piece p.  A piece that crosses
 // the end of a GEMM continues with the first wave tiles of the next one, so a workgroup runs one to
 // three GEMM segments in turn and all workgroups end together whatever the GEMMs' sizes.  Inside
 // GEMM g a piece boundary at cost b falls on wave tile floor((b - start of g) / cost of g).
-__host__ __device__ inline int64_t piece_bound(int64_t n_wt, int p) {
-    return (int64_t)p * n_wt * TOTAL_COST / WGRAD_TARGET_JOBS;
+__host__ __device__ inline int64_t piece_bound(const ArchTab& t, int64_t n_wt, int p) {
+    return (int64_t)p * n_wt * total_cost(t) / WGRAD_TARGET_JOBS;
 }
-__host__ __device__ inline int64_t bound_to_wt(int64_t n_wt, int g, int64_t b) {
-    constexpr int cost[NGEMM] = NERF_WG_COST;
+__host__ __device__ inline int64_t bound_to_wt(const ArchTab& t, int64_t n_wt, int g, int64_t b) {
     int before = 0;
-    for (int i = 0; i < g; ++i) before += cost[i];
-    int64_t w = (b - n_wt * before) / cost[g];
-    if (b < n_wt * before) w = 0;
+    for (int i = 0; i < g; ++i) before += t.cost[i];
+    if (b < n_wt * before) return 0;
+    const int64_t w = (b - n_wt * before) / t.cost[g];
     return w > n_wt ? n_wt : w;
 }
 // wave tiles [wt0, wt1) of GEMM g that belong to piece p (empty when wt1 <= wt0)
-__host__ __device__ inline void piece_segment(int64_t n_wt, int g, int p, int64_t& wt0, int64_t& wt1) {
-    wt0 = bound_to_wt(n_wt, g, piece_bound(n_wt, p));
-    wt1 = bound_to_wt(n_wt, g, piece_bound(n_wt, p + 1));
+__host__ __device__ inline void piece_segment(const ArchTab& t, int64_t n_wt, int g, int p, int64_t& wt0, int64_t& wt1) {
+    wt0 = bound_to_wt(t, n_wt, g, piece_bound(t, n_wt, p));
+    wt1 = bound_to_wt(t, n_wt, g, piece_bound(t, n_wt, p + 1));
 }
 
 struct JobTable {
@@ -96,30 +111,32 @@ struct JobTable {
     int64_t part_off[NGEMM]; // float offset of GEMM g's first partial block in the partial buffer
 };
 
-static JobTable make_jobs(int64_t n_wt) {
-    JobTable t;
+static JobTable make_jobs(const ArchTab& t, int64_t n_wt) {
+    JobTable j;
     int64_t off = 0;
     for (int g = 0; g < NGEMM; ++g) {
+        j.splits[g] = 0; j.piece0[g] = 0; j.part_off[g] = off;
+        if (g >= t.ngemm) continue;
         // first and last piece with wave tiles of this GEMM; with very few wave tiles a piece in between
         // can be empty: it then writes a zero block, so that the GEMM's blocks stay one range
         int first = -1, last = -1;
         for (int p = 0; p < WGRAD_TARGET_JOBS; ++p) {
             int64_t a, b;
-            piece_segment(n_wt, g, p, a, b);
+            piece_segment(t, n_wt, g, p, a, b);
             if (b > a) {
                 if (first < 0) first = p;
                 last = p;
             }
         }
-        t.piece0[g] = first;
-        t.splits[g] = last - first + 1;
-        t.part_off[g] = off;
-        off += (int64_t)t.splits[g] * gemm_out_floats(g);
+        j.piece0[g] = first;
+        j.splits[g] = last - first + 1;
+        off += (int64_t)j.splits[g] * gemm_out_floats(t, g);
     }
-    return t;
+    return j;
 }
-static int64_t partial_floats(const JobTable& t) {
-    return t.part_off[NGEMM - 1] + (int64_t)t.splits[NGEMM - 1] * gemm_out_floats(NGEMM - 1);
+static int64_t partial_floats(const ArchTab& t, const JobTable& j) {
+    const int g = t.ngemm - 1;
+    return j.part_off[g] + (int64_t)j.splits[g] * gemm_out_floats(t, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,7 +205,8 @@ __device__ __forceinline__ void mask_issue(const char* masks, int64_t wt, int te
 }
 __device__ __forceinline__ void mask_landed() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
-template <int PREC>
+// VIEW = false: the network without view directions (mlp_common.hpp): dZ_o = d raw is the chain's input
+template <int PREC, bool VIEW>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdArgs a) {
     typedef typename Prec<PREC>::frag frag;
     typedef typename Prec<PREC>::elem T;
@@ -208,16 +226,18 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
     const char* const mask_rd = lds + MASK_LDS_OFF + wave * 1024 + lane * 4;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    // masks of G for the first pass go first: the ring's 8 initial copies are younger
-    if ((int64_t)blockIdx.x < a.n_tiles) mask_issue(masks, (int64_t)blockIdx.x * 8 + wave, MASK_G, lds, MB_G, wave, lane);
+    // masks of the first masked layer of the first pass (G; without view directions H7) go first: the
+    // ring's 8 initial copies are younger
+    if ((int64_t)blockIdx.x < a.n_tiles)
+        mask_issue(masks, (int64_t)blockIdx.x * 8 + wave, VIEW ? MASK_G : 7, lds, VIEW ? MB_G : MB_A, wave, lane);
     Ring ring;
-    ring_init(ring, lds, a.packed + PACK_BWD_OFF, BWD_CHUNKS, lane, wave);
+    ring_init(ring, lds, a.packed + PACK_BWD_OFF, VIEW ? BWD_CHUNKS : NV_BWD_CHUNKS, lane, wave);
 
     for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t wt = tile * 8 + wave;
         const int64_t m = wt * WAVE_SAMPLES + c;
         const bool valid = m < a.M;
-        mask_issue(masks, wt, 7, lds, MB_A, wave, lane);
+        if (VIEW) mask_issue(masks, wt, 7, lds, MB_A, wave, lane);
 
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid && h == 0) {
@@ -229,10 +249,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
         frag da[H_KS + 1], db[H_KS];
         uint32_t mk[4];       // masks are fetched ahead of their tile: four tiles can be pending
 
-        // dZ10: slots 0..2 = d rgb_raw (lane half 0, elements 0..2)
+        // dZ10: slots 0..2 = d rgb_raw (lane half 0, elements 0..2); without view directions slot 3 = d sigma_raw
+        // as well: the four outputs of output_linear
 #pragma unroll
         for (int j = 0; j < 8; ++j) db[0][j] = (T)0.0f;
         db[0][0] = (T)dr.x; db[0][1] = (T)dr.y; db[0][2] = (T)dr.z;
+        if (!VIEW) db[0][3] = (T)dr.w;
         store_unit_frag<PREC>(a.dz, dz_ks0(10), DZ_KS[10], n_wt, wt, 0, lane_off, db[0]);
 
         // generic masked step: acc tile mt of d(activation saved as tensor SV) -> out[2mt], out[2mt+1],
@@ -256,9 +278,31 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
             };
         };
 #define NERF_IC(N) std::integral_constant<int, N>()
-        // d0: dG = W_r2^T dZ10, masked by G > 0  -> dZ9 (8 k-steps) in da
         mask_landed();
-        ring_enter<0>(ring, lds);            // chunk 0 of the pass: d0 starts behind the stream's front pad
+        ring_enter<0>(ring, lds);            // chunk 0 of the pass: the first layer starts behind the stream's front pad
+        if (!VIEW) {
+            // Before each masked layer: its masks have landed; the next layer's start their way into the other buffer.
+#define NERF_MASKED_NV(E, NK0, IN, BUF, NEXT_ISSUE, DZL, OUT)                                               \
+            mask_landed();                                                                                  \
+            NEXT_ISSUE;                                                                                     \
+            run_layer<PREC, nv_bwd_block0(E), 8, NK0, 0, 2>(ring, lds, IN, IN, mask_pre(NERF_IC(BUF)), mask_epi(NERF_IC(DZL), OUT));
+            // e0: dH7 = W_o^T dZ_o, masked by H7 > 0 -> dZ7 in da
+            NERF_MASKED_NV(0, 1, db, MB_A, mask_issue(masks, wt, 6, lds, MB_B, wave, lane), 7, da)
+            // e1..e6: hidden layers 6, 5 (H rows), 4, 3, 2, 1
+            NERF_MASKED_NV(1, H_KS, da, MB_B, mask_issue(masks, wt, 5, lds, MB_A, wave, lane), 6, db)
+            NERF_MASKED_NV(2, H_KS, db, MB_A, mask_issue(masks, wt, 4, lds, MB_B, wave, lane), 5, da)
+            NERF_MASKED_NV(3, H_KS, da, MB_B, mask_issue(masks, wt, 3, lds, MB_A, wave, lane), 4, db)
+            NERF_MASKED_NV(4, H_KS, db, MB_A, mask_issue(masks, wt, 2, lds, MB_B, wave, lane), 3, da)
+            NERF_MASKED_NV(5, H_KS, da, MB_B, mask_issue(masks, wt, 1, lds, MB_A, wave, lane), 2, db)
+            NERF_MASKED_NV(6, H_KS, db, MB_A, mask_issue(masks, wt, 0, lds, MB_B, wave, lane), 1, da)
+            // e7: hidden layer 0; the copy started here is the next pass's H7 mask
+            NERF_MASKED_NV(7, H_KS, da, MB_B,
+                           if (tile + gridDim.x < a.n_tiles) mask_issue(masks, (tile + gridDim.x) * 8 + wave, 7, lds, MB_A, wave, lane),
+                           0, db)
+#undef NERF_MASKED_NV
+            continue;
+        }
+        // d0: dG = W_r2^T dZ10, masked by G > 0  -> dZ9 (8 k-steps) in da
         run_layer<PREC, bwd_block0(0), 4, 1, 0, 2>(ring, lds, db, db, mask_pre(NERF_IC(MB_G)), mask_epi(NERF_IC(9), da));
         // d1: dF = W_r0[:, :256]^T dZ9 (feature_linear has no activation) -> dZ8[0..255] in db; sigma joins as k-step 16
         // (dF stays in registers: the weight gradients that would read it are factored, mlp_common.hpp)
@@ -390,7 +434,7 @@ __device__ __forceinline__ float frag_sum(const s16x8& f) {
 // NSUB wave tiles are staged and contracted per step (GEMMs with few units would otherwise keep too few
 // bytes in flight to cover the memory latency).
 template <int PREC, int A_NKS, int B_NKS, int WR, int WC, int TI, int TJ, int NSUB = 1>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char* lds, const int split,
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& tab, const int g, char* lds, const int split,
                                            const int64_t wt0, const int64_t wt1) {
     typedef typename Prec<PREC>::frag frag;
     static_assert(WR * WC <= 8 && WR * TI * 2 >= A_NKS && WC * TJ * 2 == B_NKS, "wave grid must cover the block");
@@ -398,7 +442,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const bool active = wave < WR * WC;
-    const GemmDesc gd = GEMMS[g];
+    const GemmDesc gd = tab.g[g];
 
     const int ntiles = wt1 > wt0 ? (int)(wt1 - wt0) : 0;
     const int nsteps = (ntiles + NSUB - 1) / NSUB;
@@ -548,7 +592,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
     // partial block: [R][C] row-major then R bias sums
     if (!active) return;
     constexpr int R = A_NKS * 16, C = B_NKS * 16;
-    float* out = a.partial + a.jobs.part_off[g] + (int64_t)split * gemm_out_floats(g);
+    float* out = a.partial + a.jobs.part_off[g] + (int64_t)split * gemm_out_floats(tab, g);
     const int col_l = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -569,28 +613,30 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int g, char
     }
 }
 
-template <int PREC>
+template <int PREC, bool VIEW>
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[WG_LDS_BYTES];
 #ifdef NERF_WG_STAMP
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
+    const ArchTab& tab = arch_tab<VIEW>();
     const int p = blockIdx.x;
     bool ran = false;
-    for (int g = 0; g < NGEMM; ++g) {
+    for (int g = 0; g < tab.ngemm; ++g) {
         const int split = p - a.jobs.piece0[g];
         if (split < 0 || split >= a.jobs.splits[g]) continue;          // workgroup-uniform
         int64_t wt0, wt1;
-        piece_segment(a.n_wt, g, p, wt0, wt1);
+        piece_segment(tab, a.n_wt, g, p, wt0, wt1);
         // the previous segment's last LDS reads (other waves) before this one's first copies
         if (ran) __syncthreads();
         ran = true;
         // shape dispatch: <A units, B units, wave grid, tiles per wave, wave tiles per step>
-        if (g == 0) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, g, lds, split, wt0, wt1);
-        else if (g == 5) wgrad_body<PREC, 16, 20, 4, 2, 2, 5>(a, g, lds, split, wt0, wt1);
-        else if (g == 8) wgrad_body<PREC, 9, 18, 2, 3, 3, 3>(a, g, lds, split, wt0, wt1);
-        else if (g == 9) wgrad_body<PREC, 1, 8, 1, 4, 1, 1, 4>(a, g, lds, split, wt0, wt1);
-        else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, g, lds, split, wt0, wt1);
+        if (g == 0) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, tab, g, lds, split, wt0, wt1);
+        else if (g == 5) wgrad_body<PREC, 16, 20, 4, 2, 2, 5>(a, tab, g, lds, split, wt0, wt1);
+        else if (g == 8 && VIEW) wgrad_body<PREC, 9, 18, 2, 3, 3, 3>(a, tab, g, lds, split, wt0, wt1);
+        else if (g == 8) wgrad_body<PREC, 1, 16, 1, 8, 1, 1, 2>(a, tab, g, lds, split, wt0, wt1);
+        else if (g == 9) wgrad_body<PREC, 1, 8, 1, 4, 1, 1, 4>(a, tab, g, lds, split, wt0, wt1);
+        else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, tab, g, lds, split, wt0, wt1);
     }
 #ifdef NERF_WG_STAMP
     if (a.stamps && threadIdx.x == 0) {
@@ -625,28 +671,33 @@ struct ReduceArgs {
 };
 constexpr int PROD_FLOATS = 128 * 256;
 
-__device__ __forceinline__ float sum_partials(const ReduceArgs& a, int g, int idx) {
+__device__ __forceinline__ float sum_partials(const ReduceArgs& a, const ArchTab& tab, int g, int idx) {
     const float* p = a.partial + a.jobs.part_off[g] + idx;
     const int n = a.jobs.splits[g];
-    const int stride = gemm_out_floats(g);
+    const int stride = gemm_out_floats(tab, g);
     float s = 0.f;
 #pragma unroll 8
     for (int i = 0; i < n; ++i) s += p[(int64_t)i * stride];      // fixed order; loads of eight terms in flight
     return s;
 }
 
+template <bool VIEW>
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
+    const ArchTab& tab = arch_tab<VIEW>();
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N_PARAMS + PROD_FLOATS) return;
-    if (e >= N_PARAMS) {                                // the product P, handed to mlp_post_kernel
+    if (e >= (VIEW ? N_PARAMS + PROD_FLOATS : N_PARAMS_NV)) return;
+    if (VIEW && e >= N_PARAMS) {                        // the product P, handed to mlp_post_kernel
         const int k = (e - N_PARAMS) >> 8, i = (e - N_PARAMS) & 255;
-        float v = sum_partials(a, 8, hidden_pos(k) * (gemm_b_nks(8) * 16) + hidden_pos(i));
+        float v = sum_partials(a, tab, 8, hidden_pos(k) * (gemm_b_nks(tab, 8) * 16) + hidden_pos(i));
         if (a.scale) v = v / *a.scale;
         a.prod[e - N_PARAMS] = v;
         return;
     }
     int g, row, col = -1;      // col < 0: bias element
-    if (e < OFF_W1) {                                   // pts_linears.0
+    if (!VIEW && e >= OFF_WO) {                         // output_linear: rows 0..3 of GEMM 8
+        g = 8;
+        if (e < OFF_BO) { row = (e - OFF_WO) >> 8; col = hidden_pos((e - OFF_WO) & 255); } else row = e - OFF_BO;
+    } else if (e < OFF_W1) {                                   // pts_linears.0
         g = 0;
         if (e < OFF_B0) { row = hidden_pos(e / 63); col = pe_pos(e % 63, 10); } else row = hidden_pos(e - OFF_B0);
     } else if (e < OFF_W5) {                            // pts_linears.1..4
@@ -680,9 +731,9 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
         g = 9;
         if (e < OFF_BR2) { row = (e - OFF_WR2) / 128; col = hidden_pos((e - OFF_WR2) % 128); } else row = e - OFF_BR2;
     }
-    const int R = gemm_a_nks(g) * 16, C = gemm_b_nks(g) * 16;
+    const int R = gemm_a_nks(tab, g) * 16, C = gemm_b_nks(tab, g) * 16;
     const int idx = col >= 0 ? row * C + col : R * C + row;
-    float v = sum_partials(a, g, idx);
+    float v = sum_partials(a, tab, g, idx);
     if (a.scale) v = v / *a.scale;
     a.d_params[e] = v;
 }
@@ -734,8 +785,10 @@ static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 
 extern "C" int64_t nerf_mlp_partial_bytes(int64_t n_samples) {
     const int64_t n_wt = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
-    const JobTable t = make_jobs(n_wt > 0 ? n_wt : 1);
-    return round_up(partial_floats(t) * 4, 256) + (int64_t)PROD_FLOATS * 4;     // partial blocks, then the product P
+    // enough for either architecture
+    const int64_t a = partial_floats(TAB_VIEW, make_jobs(TAB_VIEW, n_wt > 0 ? n_wt : 1));
+    const int64_t b = partial_floats(TAB_NOVIEW, make_jobs(TAB_NOVIEW, n_wt > 0 ? n_wt : 1));
+    return round_up((a > b ? a : b) * 4, 256) + (int64_t)PROD_FLOATS * 4;     // partial blocks, then the product P
 }
 
 extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) {
@@ -745,7 +798,7 @@ extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) {
 
 static int check_bwd_common(int64_t M, int precision) {
     NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
     return NERF_OK;
 }
 
@@ -753,6 +806,18 @@ extern "C" int64_t nerf_mlp_dz_bytes(int64_t n_samples) {
     const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
     return round_up(n_tiles * 8 * (int64_t)DZ_UNITS * 1024, 256);
 }
+
+// launch K<PREC, VIEW> for the runtime (precision, view)
+#define NERF_LAUNCH_ARCH(K, GRID, BLOCK, ST, ARG)                                                              \
+    do {                                                                                                       \
+        if (prec == NERF_PREC_BF16) {                                                                          \
+            if (view) hipLaunchKernelGGL((K<NERF_PREC_BF16, true>), GRID, BLOCK, 0, ST, ARG);                  \
+            else hipLaunchKernelGGL((K<NERF_PREC_BF16, false>), GRID, BLOCK, 0, ST, ARG);                      \
+        } else {                                                                                               \
+            if (view) hipLaunchKernelGGL((K<NERF_PREC_FP16, true>), GRID, BLOCK, 0, ST, ARG);                  \
+            else hipLaunchKernelGGL((K<NERF_PREC_FP16, false>), GRID, BLOCK, 0, ST, ARG);                      \
+        }                                                                                                      \
+    } while (0)
 
 extern "C" int nerf_mlp_bwd_data(int64_t M, const float* d_raw, const void* packed, int precision,
                                  const void* saved, const float* grad_scale, void* dz, void* stream) {
@@ -762,14 +827,15 @@ extern "C" int nerf_mlp_bwd_data(int64_t M, const float* d_raw, const void* pack
     NERF_REQUIRE(d_raw && packed && saved && dz, NERF_E_NULL);
     NERF_REQUIRE(nerf_aligned(d_raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
                      nerf_aligned(dz, 256), NERF_E_ALIGN);
+    const bool view = !(precision & NERF_ARCH_NOVIEW);
+    const int prec = precision & ~NERF_ARCH_NOVIEW;
     const int64_t n_tiles = (M + TILE_SAMPLES - 1) / TILE_SAMPLES;
     BwdArgs b{};
     b.M = M; b.n_tiles = n_tiles; b.d_raw = d_raw; b.packed = (const char*)packed; b.saved = (const char*)saved;
     b.dz = (char*)dz; b.scale = grad_scale;
     const dim3 gb((unsigned)(n_tiles < 256 ? n_tiles : 256)), tb(CHAIN_THREADS);
     hipStream_t st = (hipStream_t)stream;
-    if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_BF16>, gb, tb, 0, st, b);
-    else hipLaunchKernelGGL(mlp_dgrad_kernel<NERF_PREC_FP16>, gb, tb, 0, st, b);
+    NERF_LAUNCH_ARCH(mlp_dgrad_kernel, gb, tb, st, b);
     return nerf_launch_status();
 }
 
@@ -779,17 +845,20 @@ extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* packed, const void* s
     int rc = check_bwd_common(M, precision);
     if (rc) return rc;
     NERF_REQUIRE(d_params, NERF_E_NULL);
+    const bool view = !(precision & NERF_ARCH_NOVIEW);
+    const int prec = precision & ~NERF_ARCH_NOVIEW;
+    const ArchTab& tab = view ? TAB_VIEW : TAB_NOVIEW;
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) {
-        hipError_t e = hipMemsetAsync(d_params, 0, sizeof(float) * N_PARAMS, st);
+        hipError_t e = hipMemsetAsync(d_params, 0, sizeof(float) * (view ? N_PARAMS : N_PARAMS_NV), st);
         return e == hipSuccess ? NERF_OK : (int)e;
     }
     NERF_REQUIRE(packed && saved && dz && partial, NERF_E_NULL);
     NERF_REQUIRE(nerf_aligned(packed, 256) && nerf_aligned(saved, 256) && nerf_aligned(dz, 256) &&
                      nerf_aligned(partial, 256), NERF_E_ALIGN);
     const int64_t n_wt = (M + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
-    const JobTable jobs = make_jobs(n_wt);
-    const int64_t prod_off = round_up(partial_floats(jobs) * 4, 256);
+    const JobTable jobs = make_jobs(tab, n_wt);
+    const int64_t prod_off = round_up(partial_floats(tab, jobs) * 4, 256);
     NERF_REQUIRE(partial_bytes >= prod_off + (int64_t)PROD_FLOATS * 4, NERF_E_WORKSPACE);
 
     WgradArgs w{};
@@ -801,15 +870,18 @@ extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* packed, const void* s
     }
 #endif
     const dim3 gw((unsigned)WGRAD_TARGET_JOBS), tw(512);
-    if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_BF16>, gw, tw, 0, st, w);
-    else hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_FP16>, gw, tw, 0, st, w);
+    NERF_LAUNCH_ARCH(mlp_wgrad_kernel, gw, tw, st, w);
     rc = nerf_launch_status();
     if (rc) return rc;
 
     ReduceArgs r{};
     r.partial = (const float*)partial; r.d_params = d_params; r.scale = grad_scale; r.jobs = jobs;
     r.prod = reinterpret_cast<float*>((char*)partial + prod_off);
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((N_PARAMS + PROD_FLOATS + 255) / 256), dim3(256), 0, st, r);
+    if (!view) {
+        hipLaunchKernelGGL(mlp_reduce_kernel<false>, dim3((N_PARAMS_NV + 255) / 256), dim3(256), 0, st, r);
+        return nerf_launch_status();
+    }
+    hipLaunchKernelGGL(mlp_reduce_kernel<true>, dim3((N_PARAMS + PROD_FLOATS + 255) / 256), dim3(256), 0, st, r);
     rc = nerf_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(mlp_post_kernel, dim3((POST_OUTPUTS + 255) / 256), dim3(256), 0, st, r.prod,

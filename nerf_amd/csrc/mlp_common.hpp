@@ -167,6 +167,28 @@ __host__ __device__ constexpr int pe16_feature(int L, int g, int q) {
     return -1;
 }
 
+// ---- the network without view directions (use_viewdirs=False, nerf.py:151-153 and :202-206) -----------
+// L0..L7 as above, then  L8  output_linear  H(256) -> 4 = (rgb_raw, sigma_raw).  Its parameters follow
+// pts_linears.7 in the flat buffer.  The streams keep L0..L7 where they are and end with the one output
+// layer: training forward 16 blocks (one 32-row tile x 16 k-steps), inference 8 blocks (one 16-row tile x
+// 8 k-steps); the backward stream starts with dH7 = W_o^T dZ_o (8 tiles x 1 k-step) and goes on with the
+// hidden layers 7..1.  Saved activations, masks and dZ use the same unit tables (the view-direction and
+// colour-head tensors stay unused; dZ_o takes the place of dZ10).
+constexpr int OFF_WO = OFF_WS;                  constexpr int OFF_BO = OFF_WO + 4 * 256;
+constexpr int N_PARAMS_NV = OFF_BO + 4;
+static_assert(N_PARAMS_NV == NERF_MLP_NPARAMS_NOVIEW, "parameter count");
+constexpr int NV_FWD_BLOCKS_REAL = fwd_block0(8) + 16;                                    // 992
+constexpr int NV_FWD_CHUNKS = (NV_FWD_BLOCKS_REAL + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;     // 31
+constexpr int NV_F16_BLOCKS_REAL = f16_block0(8) + 8;                                     // 976
+constexpr int NV_F16_CHUNKS = (NV_F16_BLOCKS_REAL + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;     // 31
+constexpr int NV_NBWD = 8;        // e = 0: output layer, e = 1..7: hidden layers 7..1 (= d3..d9 above)
+constexpr int NV_BWD_PAD = 8;     // puts the pair ends of e1..e7 at block 16 of their chunk
+constexpr int nv_bwd_block0(int e) { return NV_BWD_PAD + (e > 0 ? 8 + (e - 1) * 128 : 0); }
+constexpr int NV_BWD_BLOCKS_REAL = nv_bwd_block0(NV_NBWD);                                // 912
+constexpr int NV_BWD_CHUNKS = (NV_BWD_BLOCKS_REAL + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;     // 29
+static_assert(NV_FWD_BLOCKS_REAL == 992 && NV_F16_BLOCKS_REAL == 976 && NV_BWD_BLOCKS_REAL == 912 &&
+              nv_bwd_block0(1) % CHUNK_BLOCKS == 16, "streams of the network without view directions");
+
 // ---- packed buffer layout ----------------------------------------------------------------------
 constexpr int64_t PACK_FWD_OFF = 0;
 constexpr int64_t PACK_BWD_OFF = PACK_FWD_OFF + (int64_t)FWD_BLOCKS * BLOCK_BYTES;

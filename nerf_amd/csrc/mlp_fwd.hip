@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void encode_units_kernel(int64_t M, int64_t n_
         for (int j = 0; j < 8; ++j) {
             const int feat = pe_combo_feature(8 * ks + j, h, view ? 4 : 10);
             float v = 0.0f;
-            if (m < M && feat >= 0) v = view ? x_views[m * VPE_FEATS + feat] : x_pts[m * PE_FEATS + feat];
+            if (m < M && feat >= 0) v = view ? (x_views ? x_views[m * VPE_FEATS + feat] : 0.0f) : x_pts[m * PE_FEATS + feat];
             f[j] = (T)v;
         }
         char* dst = view ? vpe_units + (wt * VPE_KS + ks) * 1024 : pe_units + (wt * PE_KS + ks) * 1024;
@@ -130,7 +130,8 @@ __device__ __forceinline__ uint32_t sign_bits(const typename Prec<PREC>::frag& f
     return m;
 }
 
-template <int PREC, bool SAVE, bool ENCODED>
+// VIEW = false: the network without view directions (output_linear follows L7; mlp_common.hpp)
+template <int PREC, bool SAVE, bool ENCODED, bool VIEW>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs a) {
     typedef typename Prec<PREC>::frag frag;
     __shared__ __attribute__((aligned(16))) char lds[CHAIN_LDS_BYTES];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
     __syncthreads();
 
     Ring ring;
-    ring_init(ring, lds, a.packed + PACK_FWD_OFF, FWD_CHUNKS, lane, wave);
+    ring_init(ring, lds, a.packed + PACK_FWD_OFF, VIEW ? FWD_CHUNKS : NV_FWD_CHUNKS, lane, wave);
     const int64_t n_wt = a.n_tiles * 8;
     char* const mask_base = SAVE ? a.saved + (size_t)n_wt * SAVED_UNITS * 1024 : nullptr;
 
@@ -221,6 +222,14 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
         run_layer<PREC, fwd_block0(6), 8, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(6), hidden(NERF_IC(6), ha));
         run_layer<PREC, fwd_block0(7), 8, H_KS, 0, SV>(ring, lds, ha, ha, NERF_BIAS(7), hidden(NERF_IC(7), hb));
 
+        if (!VIEW) {
+            // L8 of the network without view directions: output_linear -> rows 0..3 = (rgb_raw, sigma_raw)
+            run_layer<PREC, fwd_block0(8), 1, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(8), [&](int, const f32x16& acc) {
+                if (valid && h == 0)
+                    reinterpret_cast<float4*>(a.raw)[m] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            });
+            continue;
+        }
         // L8: feature_linear (no activation) -> ha, sigma_linear -> row 0 of tile 8
         float sigma = 0.f;
         run_layer<PREC, fwd_block0(8), 9, H_KS, 0, 0>(ring, lds, hb, hb, NERF_BIAS(8), [&](int mt, const f32x16& acc) {
@@ -277,6 +286,8 @@ extern "C" int64_t nerf_mlp_saved_bytes(int64_t n_samples) {
 }
 
 static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* stream) {
+    const bool view = !(precision & NERF_ARCH_NOVIEW);
+    precision &= ~NERF_ARCH_NOVIEW;
     NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
     NERF_REQUIRE(encoded || a.saved != nullptr, NERF_E_NULL);
     if (a.M == 0) return NERF_OK;
@@ -284,7 +295,8 @@ static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* strea
     const dim3 g((unsigned)grid), b(CHAIN_THREADS);
     hipStream_t st = (hipStream_t)stream;
     const bool save = a.saved != nullptr;
-#define NERF_LAUNCH(P, SV, EN) hipLaunchKernelGGL((mlp_fwd_kernel<P, SV, EN>), g, b, 0, st, a)
+#define NERF_LAUNCH(P, SV, EN) do { if (view) hipLaunchKernelGGL((mlp_fwd_kernel<P, SV, EN, true>), g, b, 0, st, a); \
+                                    else hipLaunchKernelGGL((mlp_fwd_kernel<P, SV, EN, false>), g, b, 0, st, a); } while (0)
 #define NERF_PICK(P)                                            \
     if (save) { if (encoded) NERF_LAUNCH(P, true, true); else NERF_LAUNCH(P, true, false); } \
     else { NERF_LAUNCH(P, false, true); }      /* fused inference is mlp_fwd16.hip's */
@@ -303,7 +315,7 @@ extern "C" int nerf_mlp_fwd(int64_t n_rays, int S, const float* rays_o, const fl
     NERF_REQUIRE(rays_o && rays_d && z && packed && raw, NERF_E_NULL);
     NERF_REQUIRE(n_rays >= 0 && S >= 1, NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256), NERF_E_ALIGN);
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
     if (saved == nullptr) return nerf_mlp_fwd16_launch(n_rays, S, rays_o, rays_d, z, packed, precision, raw, stream);
     FwdArgs a{};
     a.M = n_rays * S; a.n_tiles = (a.M + TILE_SAMPLES - 1) / TILE_SAMPLES; a.S = S;
@@ -331,7 +343,7 @@ static int fwd_encoded_impl(int64_t M, const float* x_pts, const float* x_views,
     const int64_t threads = n_wt * (PE_KS + VPE_KS) * 64;
     int64_t blocks = (threads + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (precision == NERF_PREC_BF16)
+    if ((precision & ~NERF_ARCH_NOVIEW) == NERF_PREC_BF16)
         hipLaunchKernelGGL(encode_units_kernel<NERF_PREC_BF16>, dim3((unsigned)blocks), dim3(256), 0,
                            (hipStream_t)stream, M, n_wt, x_pts, x_views, pe_units, vpe_units);
     else
@@ -344,12 +356,13 @@ static int fwd_encoded_impl(int64_t M, const float* x_pts, const float* x_views,
 
 extern "C" int nerf_mlp_fwd_encoded(int64_t M, const float* x_pts, const float* x_views, const void* packed,
                                     int precision, float* raw, void* saved, void* workspace, void* stream) {
-    NERF_REQUIRE(x_pts && x_views && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(x_pts && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(x_views || (precision & NERF_ARCH_NOVIEW), NERF_E_NULL);
     NERF_REQUIRE(saved || workspace, NERF_E_NULL);
     NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
                  nerf_aligned(workspace, 256), NERF_E_ALIGN);
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
     if (M == 0) return NERF_OK;
     return fwd_encoded_impl(M, x_pts, x_views, packed, precision, raw, saved, workspace, stream);
 }
@@ -393,10 +406,11 @@ extern "C" int64_t nerf_mlp_fwd_encoded_static_max_samples(void) { return NERF_M
 
 extern "C" int nerf_mlp_fwd_encoded_static(int64_t M, const float* x_pts, const float* x_views, const void* packed,
                                            int precision, float* raw, void* stream) {
-    NERF_REQUIRE(x_pts && x_views && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(x_pts && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(x_views || (precision & NERF_ARCH_NOVIEW), NERF_E_NULL);
     NERF_REQUIRE(M >= 0 && M <= NERF_MLP_FWD_ENCODED_STATIC_MAX, NERF_E_SHAPE);      // beyond the static buffer
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256), NERF_E_ALIGN);
-    NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
+    NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
     if (M == 0) return NERF_OK;
     void* ws = nullptr;
     const int rc = scratch_address(&ws);

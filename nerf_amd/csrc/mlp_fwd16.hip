@@ -107,7 +107,8 @@ __device__ __forceinline__ void tile16_to_frag(const f32x4& acc, int rt, typenam
     for (int r = 0; r < 4; ++r) f[4 * (rt & 1) + r] = (T)(RELU ? relu_bits(acc[r]) : acc[r]);
 }
 
-template <int PREC>
+// VIEW = false: the network without view directions (output_linear follows L7; mlp_common.hpp)
+template <int PREC, bool VIEW>
 __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16Args a) {
     typedef typename Prec<PREC>::frag frag;
     __shared__ __attribute__((aligned(16))) char lds[FWD16_LDS_BYTES];
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
     __syncthreads();
 
     Ring ring;
-    ring_init(ring, lds, a.packed + PACK_F16_OFF, F16_CHUNKS, lane, wave);
+    ring_init(ring, lds, a.packed + PACK_F16_OFF, VIEW ? F16_CHUNKS : NV_F16_CHUNKS, lane, wave);
 
     // Inputs of a pass.  issue_inputs() starts the copies (it must directly follow a chunk entry, see
     // ring_enter's SIDE); read_inputs() turns what has landed into points and unit view directions.
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
         const int64_t wt = tile * 8 + wave;
         const bool has_next = tile + gridDim.x < a.n_tiles;
         frag vpe[1][2];
-        view_encoding(vpe);
+        if (VIEW) view_encoding(vpe);
         const bool valid0 = wt * WAVE_SAMPLES + n < a.M, valid1 = wt * WAVE_SAMPLES + 16 + n < a.M;
 
         frag ha[8][2], hb[8][2];
@@ -208,6 +209,19 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
         if (has_next) { issue_inputs(tile + gridDim.x); ring.extra_enters = 2; }   // land during L7 and L8
         run_layer16<PREC, f16_block0(7), 16, 8, 0>(ring, lds, ha, ha, bias(7), hidden(hb));
 
+        if (!VIEW) {
+            // L8 of the network without view directions: output_linear, rows 0..3 (lane group 0) = (rgb_raw, sigma_raw)
+            run_layer16<PREC, f16_block0(8), 1, 8, 0>(ring, lds, hb, hb, bias(8),
+                                                      [&](int, const f32x4& c0, const f32x4& c1) {
+                if (g == 0) {
+                    const int64_t m0 = wt * WAVE_SAMPLES + n;
+                    if (valid0) reinterpret_cast<float4*>(a.raw)[m0] = make_float4(c0[0], c0[1], c0[2], c0[3]);
+                    if (valid1) reinterpret_cast<float4*>(a.raw)[m0 + 16] = make_float4(c1[0], c1[1], c1[2], c1[3]);
+                }
+            });
+            if (has_next) point_encoding(pe);
+            continue;
+        }
         // L8: feature_linear (no activation) -> ha, sigma_linear -> row 0 of row tile 16 (lane group 0)
         float sigma[2] = {0.f, 0.f};
         run_layer16<PREC, f16_block0(8), 17, 8, 0>(ring, lds, hb, hb, bias(8),
@@ -250,7 +264,15 @@ int nerf_mlp_fwd16_launch(int64_t n_rays, int S, const float* rays_o, const floa
     if (a.M == 0) return NERF_OK;
     const int64_t grid = a.n_tiles < 256 ? a.n_tiles : 256;   // one persistent workgroup per CU
     const dim3 g((unsigned)grid), b(CHAIN_THREADS);
-    if (precision == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_fwd16_kernel<NERF_PREC_BF16>, g, b, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(mlp_fwd16_kernel<NERF_PREC_FP16>, g, b, 0, (hipStream_t)stream, a);
+    const bool view = !(precision & NERF_ARCH_NOVIEW);
+    precision &= ~NERF_ARCH_NOVIEW;
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == NERF_PREC_BF16) {
+        if (view) hipLaunchKernelGGL((mlp_fwd16_kernel<NERF_PREC_BF16, true>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((mlp_fwd16_kernel<NERF_PREC_BF16, false>), g, b, 0, st, a);
+    } else {
+        if (view) hipLaunchKernelGGL((mlp_fwd16_kernel<NERF_PREC_FP16, true>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((mlp_fwd16_kernel<NERF_PREC_FP16, false>), g, b, 0, st, a);
+    }
     return nerf_launch_status();
 }

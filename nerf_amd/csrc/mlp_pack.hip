@@ -103,8 +103,14 @@ __device__ __forceinline__ float bias_value(const float* __restrict__ P, int L, 
 // One thread produces one lane's 16-byte fragment of one block (or one fp32 of the bias / post tables).
 // `streams`: NERF_PACK_TRAIN = forward + backward streams and the post table, NERF_PACK_INFER = the
 // inference stream; the bias table is always written.
+// ---- the network without view directions: L0..L7 from the functions above, then output_linear ----
+__device__ __forceinline__ float nv_out_weight(const float* __restrict__ P, int row, int slot) {
+    return row < 4 ? P[OFF_WO + row * 256 + slot] : 0.0f;
+}
+
 template <int PREC>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, char* __restrict__ out, int streams) {
+    const bool noview = streams & NERF_PACK_NOVIEW;
     typedef typename Prec<PREC>::elem T;
     typedef typename Prec<PREC>::frag frag;
     frag* fwd = reinterpret_cast<frag*>(out + PACK_FWD_OFF);
@@ -125,7 +131,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
             frag f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = (T)0.0f;
-            if (b >= FWD_PAD && b < FWD_BLOCKS_REAL) {
+            if (noview && b >= fwd_block0(8)) {
+                const int ks = b - fwd_block0(8);             // one 32-row tile, 16 k-steps in order
+                if (ks < 16) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = (T)nv_out_weight(P, lane & 31, slot_of(ks, lane >> 5, j));
+                }
+            } else if (b >= FWD_PAD && b < FWD_BLOCKS_REAL) {
                 b -= FWD_PAD;
                 int L = 0;
                 while (L + 1 < NLAYERS && b >= FWD_TILES[L] * FWD_KS[L]) { b -= FWD_TILES[L] * FWD_KS[L]; ++L; }
@@ -143,7 +155,25 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
             frag f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = (T)0.0f;
-            if (b >= BWD_PAD && b < BWD_BLOCKS_REAL) {
+            if (noview) {
+                if (b >= NV_BWD_PAD && b < NV_BWD_BLOCKS_REAL) {
+                    b -= NV_BWD_PAD;
+                    if (b < 8) {          // dH7 = W_o^T dZ_o: tile b, one k-step, slots 0..3 = the four outputs
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = slot_of(0, lane >> 5, j);
+                            f[j] = (T)(k < 4 ? P[OFF_WO + k * 256 + 32 * b + (lane & 31)] : 0.0f);
+                        }
+                    } else {              // hidden layers 7..1 = d3..d9 of the full network
+                        b -= 8;
+                        const int d = 3 + b / 128;
+                        b %= 128;
+                        const int m = stream_tile(8, 16, b), ks = stream_ks(8, 16, b);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] = (T)bwd_weight(P, d, 32 * m + (lane & 31), slot_of(ks, lane >> 5, j));
+                    }
+                }
+            } else if (b >= BWD_PAD && b < BWD_BLOCKS_REAL) {
                 b -= BWD_PAD;
                 int d = 0;
                 while (d + 1 < NBWD && b >= BWD_TILES[d] * BWD_KS[d]) { b -= BWD_TILES[d] * BWD_KS[d]; ++d; }
@@ -154,7 +184,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
             bwd[eb] = f;
         } else if (e < E_F16) {
             const int i = (int)(e - E_BIAS);
-            bias[i] = bias_value(P, i / BIAS_STRIDE, i % BIAS_STRIDE);
+            const int L = i / BIAS_STRIDE, row = i % BIAS_STRIDE;
+            bias[i] = (noview && L >= 8) ? ((L == 8 && row < 4) ? P[OFF_BO + row] : 0.0f) : bias_value(P, L, row);
         } else if (e < E_POST) {
             if (!infer) continue;
             const int64_t ef = e - E_F16;
@@ -163,7 +194,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
             frag f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = (T)0.0f;
-            if (b >= F16_PAD && b < F16_BLOCKS_REAL) {
+            if (noview && b >= f16_block0(8)) {
+                const int ks = b - f16_block0(8);             // one 16-row tile, 8 k-steps in order
+                if (ks < 8 && (lane & 15) < 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = (T)nv_out_weight(P, lane & 15, slot16(ks, lane >> 4, j));
+                }
+            } else if (b >= F16_PAD && b < F16_BLOCKS_REAL) {
                 b -= F16_PAD;
                 int L = 0;
                 while (L + 1 < NLAYERS && b >= F16_TILES[L] * F16_KS[L]) { b -= F16_TILES[L] * F16_KS[L]; ++L; }
@@ -177,7 +214,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
             }
             f16[ef] = f;
         } else {
-            if (!train) continue;
+            if (!train || noview) continue;
             const int i = (int)(e - E_POST);
             float v;
             if (i < POST_BF) { const int in = i >> 8, o = i & 255; v = (float)(T)P[OFF_WF + o * 256 + in]; }   // W_f transposed
@@ -195,7 +232,8 @@ extern "C" int64_t nerf_mlp_packed_bytes(void) { return nerf::mlp::PACK_BYTES; }
 
 extern "C" int nerf_mlp_pack(const float* params, int precision, int streams, void* packed, void* stream) {
     NERF_REQUIRE(params && packed, NERF_E_NULL);
-    NERF_REQUIRE(streams >= 1 && streams <= (NERF_PACK_TRAIN | NERF_PACK_INFER), NERF_E_SHAPE);
+    if (precision & NERF_ARCH_NOVIEW) { precision &= ~NERF_ARCH_NOVIEW; streams |= NERF_PACK_NOVIEW; }
+    NERF_REQUIRE((streams & (NERF_PACK_TRAIN | NERF_PACK_INFER)) != 0 && (streams & ~(NERF_PACK_TRAIN | NERF_PACK_INFER | NERF_PACK_NOVIEW)) == 0, NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(packed, 256), NERF_E_ALIGN);
     NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
     const dim3 grid(1024), block(256);

@@ -100,8 +100,10 @@ class NeRF(nn.Module):
 
     # -- kernel plumbing ------------------------------------------------------------------
     def kernel_supported(self) -> bool:
-        return (self.D == 8 and self.W == 256 and self.input_ch_pts == 63 and self.input_ch_views == 27
-                and list(self.skips) == [4] and self.use_viewdirs)
+        """The two networks the reference's scripts build (train_nerf.py:189-200): 8 x 256 with the skip after
+        layer 4, with the view-direction head or (the script default) without it."""
+        return (self.D == 8 and self.W == 256 and self.input_ch_pts == 63 and list(self.skips) == [4]
+                and (self.input_ch_views == 27 or not self.use_viewdirs))
 
     def fused(self) -> bool:
         """True when calls go to the fused 16-bit MFMA kernels."""
@@ -116,8 +118,8 @@ class NeRF(nn.Module):
     def _require_supported(self):
         if not self.kernel_supported():
             raise NotImplementedError(
-                "the HIP MLP kernels implement D=8, W=256, input_ch_pts=63, input_ch_views=27, skips=[4], "
-                f"use_viewdirs=True; got D={self.D}, W={self.W}, pts={self.input_ch_pts}, "
+                "the 16-bit HIP MLP kernels implement D=8, W=256, input_ch_pts=63, skips=[4], with "
+                f"input_ch_views=27 or use_viewdirs=False; got D={self.D}, W={self.W}, pts={self.input_ch_pts}, "
                 f"views={self.input_ch_views}, skips={list(self.skips)}, use_viewdirs={self.use_viewdirs}")
         if self.precision not in _FUSED_PRECISIONS:
             raise ValueError(f"the fused kernels take precision 'bf16' or 'fp16', got {self.precision!r}")
@@ -148,7 +150,8 @@ class NeRF(nn.Module):
                     flat = torch.cat([p.detach().reshape(-1) for p in ps])
                 # a training step only ever runs the training kernels on this snapshot of the weights
                 self._packed = ops.mlp_pack(flat, self.precision,
-                                            ops.PACK_TRAIN if training else ops.PACK_TRAIN | ops.PACK_INFER)
+                                            ops.PACK_TRAIN if training else ops.PACK_TRAIN | ops.PACK_INFER,
+                                            viewdirs=self.use_viewdirs)
             self._pack_key = key
         return self._packed
 
@@ -157,21 +160,23 @@ class NeRF(nn.Module):
         if not self.fused():
             raise NotImplementedError("forward_rays is the fused 16-bit path; in fp32 mode call render_rays or forward")
         return ops.fused_mlp_rays(rays_o, rays_d, z_vals, self.precision, self.packed_weights(),
-                                  self.ordered_params())
+                                  self.ordered_params(), viewdirs=self.use_viewdirs)
 
     def forward(self, x_pts_encoded: torch.Tensor, x_views_encoded: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.use_viewdirs and x_views_encoded is None:
             raise ValueError("View directions (x_views_encoded) must be provided when use_viewdirs is True.")
         if not self.fused():
             return self._forward_fp32(x_pts_encoded, x_views_encoded)
-        if x_pts_encoded.shape[-1] != 63 or x_views_encoded.shape[-1] != 27:
+        if not self.use_viewdirs:
+            x_views_encoded = None          # ignored, as nerf.py:202-206 does
+        if x_pts_encoded.shape[-1] != 63 or (x_views_encoded is not None and x_views_encoded.shape[-1] != 27):
             raise ValueError("expected encoded inputs of width 63 and 27")
-        if x_pts_encoded.shape[:-1] != x_views_encoded.shape[:-1]:
+        if x_views_encoded is not None and x_pts_encoded.shape[:-1] != x_views_encoded.shape[:-1]:
             raise ValueError("x_pts_encoded and x_views_encoded must agree on the leading dimensions")
-        if x_pts_encoded.requires_grad or x_views_encoded.requires_grad:
+        if x_pts_encoded.requires_grad or (x_views_encoded is not None and x_views_encoded.requires_grad):
             raise NotImplementedError("gradients with respect to the encoded inputs are not implemented")
         return ops.fused_mlp_encoded(x_pts_encoded, x_views_encoded, self.precision, self.packed_weights(),
-                                     self.ordered_params())
+                                     self.ordered_params(), viewdirs=self.use_viewdirs)
 
 
     # -- fp32 validation mode -----------------------------------------------------------------
@@ -331,9 +336,11 @@ def render_rays(nerf_model, embed_fn_pts, embed_fn_views, rays_o: torch.Tensor, 
     else:
         z_vals = ops.place_samples(n_rays, near, far, N_samples, lindisp, dev, z_vals_override, t_rand)
 
-    fused = (isinstance(nerf_model, NeRF) and nerf_model.fused() and use_viewdirs
+    # a network built without view directions ignores them whatever use_viewdirs says (nerf.py:202-206)
+    fused = (isinstance(nerf_model, NeRF) and nerf_model.fused()
              and isinstance(embed_fn_pts, PositionalEncoder) and embed_fn_pts.is_standard(10)
-             and isinstance(embed_fn_views, PositionalEncoder) and embed_fn_views.is_standard(4))
+             and (not nerf_model.use_viewdirs
+                  or (use_viewdirs and isinstance(embed_fn_views, PositionalEncoder) and embed_fn_views.is_standard(4))))
     if fused:
         raw = nerf_model.forward_rays(rays_o, rays_d, z_vals)
     else:

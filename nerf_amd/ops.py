@@ -362,16 +362,24 @@ def sample_merge(z_coarse: torch.Tensor, weights_coarse: torch.Tensor, N_fine: i
 PACK_TRAIN, PACK_INFER = 1, 2
 
 
-def mlp_pack(flat_params: torch.Tensor, precision: str, streams: int = PACK_TRAIN | PACK_INFER) -> torch.Tensor:
+def _prec(precision: str, viewdirs: bool) -> int:
+    """The `precision` argument of the C entry points: operand type plus the architecture flag."""
+    return _C.PREC[precision] | (0 if viewdirs else _C.ARCH_NOVIEW)
+
+
+def mlp_pack(flat_params: torch.Tensor, precision: str, streams: int = PACK_TRAIN | PACK_INFER,
+             viewdirs: bool = True) -> torch.Tensor:
     """Weight streams of one network.  ``streams`` limits the work to what the caller will run:
     PACK_TRAIN (forward that keeps activations, encoded-input forward, backward) and / or PACK_INFER
-    (the no_grad ray forward); streams that are not written hold garbage."""
+    (the no_grad ray forward); streams that are not written hold garbage.  ``viewdirs=False``: the
+    parameters are those of ``NeRF(use_viewdirs=False)``."""
     flat = _gpu_f32(flat_params, "flat_params")
-    if flat.numel() != _C.NERF_MLP_NPARAMS:
-        raise ValueError(f"expected {_C.NERF_MLP_NPARAMS} parameters, got {flat.numel()}")
+    n = _C.NERF_MLP_NPARAMS if viewdirs else _C.NERF_MLP_NPARAMS_NOVIEW
+    if flat.numel() != n:
+        raise ValueError(f"expected {n} parameters, got {flat.numel()}")
     packed = torch.empty((int(lib.nerf_mlp_packed_bytes()),), dtype=torch.uint8, device=flat.device)
     with torch.cuda.device(flat.device):
-        check(lib.nerf_mlp_pack(_p(flat), _C.PREC[precision], int(streams), _p(packed), _stream(flat.device)),
+        check(lib.nerf_mlp_pack(_p(flat), _prec(precision, viewdirs), int(streams), _p(packed), _stream(flat.device)),
               "nerf_mlp_pack")
     return packed
 
@@ -380,7 +388,7 @@ class _FusedMLP(torch.autograd.Function):
     """(rays_o, rays_d, z) or (x_pts, x_views) + 24 parameter tensors -> raw [M,4]."""
 
     @staticmethod
-    def forward(ctx, mode, a0, a1, a2, precision, packed, need_grad, *params):
+    def forward(ctx, mode, a0, a1, a2, precision, packed, need_grad, viewdirs, *params):
         dev = a0.device
         if mode == "rays":
             rays_o, rays_d, z = _gpu_f32(a0, "rays_o"), _gpu_f32(a1, "rays_d"), _gpu_f32(a2, "z_vals")
@@ -388,14 +396,15 @@ class _FusedMLP(torch.autograd.Function):
             M = N * S
             out_shape = (N, S, 4)
         else:
-            x_pts, x_views = _gpu_f32(a0, "x_pts_encoded"), _gpu_f32(a1, "x_views_encoded")
+            x_pts = _gpu_f32(a0, "x_pts_encoded")
+            x_views = _gpu_f32(a1, "x_views_encoded") if viewdirs else None
             M = x_pts.numel() // 63
             out_shape = x_pts.shape[:-1] + (4,)
         raw = torch.empty(out_shape, dtype=torch.float32, device=dev)
         saved = None
         if need_grad:
             saved = torch.empty((int(lib.nerf_mlp_saved_bytes(M)),), dtype=torch.uint8, device=dev)
-        prec = _C.PREC[precision]
+        prec = _prec(precision, viewdirs)
         with torch.cuda.device(dev):
             if mode == "rays":
                 with _timed("mlp_fwd_train" if need_grad else "mlp_fwd", dev, M):
@@ -408,6 +417,8 @@ class _FusedMLP(torch.autograd.Function):
                                                _p(work), _stream(dev)), "nerf_mlp_fwd_encoded")
         ctx.M = M
         ctx.prec = prec
+        ctx.n_params = _C.NERF_MLP_NPARAMS if viewdirs else _C.NERF_MLP_NPARAMS_NOVIEW
+        ctx.fp16 = precision == "fp16"
         ctx.shapes = [p.shape for p in params]
         ctx.packed = packed
         ctx.saved_acts = saved
@@ -423,9 +434,9 @@ class _FusedMLP(torch.autograd.Function):
         dz = torch.empty((int(lib.nerf_mlp_dz_bytes(M)),), dtype=torch.uint8, device=dev)
         part_bytes = int(lib.nerf_mlp_partial_bytes(M))
         part = torch.empty((part_bytes,), dtype=torch.uint8, device=dev)
-        d_flat = torch.empty((_C.NERF_MLP_NPARAMS,), dtype=torch.float32, device=dev)
+        d_flat = torch.empty((ctx.n_params,), dtype=torch.float32, device=dev)
         scale = None
-        if ctx.prec == _C.PREC["fp16"]:
+        if ctx.fp16:
             # keep gradients inside the fp16 range: a power-of-two scale that puts max|d_raw| near 2^10
             amax = d_raw.abs().amax().clamp_min(1e-30)
             scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)).clamp(-24.0, 24.0)).reshape(1)
@@ -446,17 +457,19 @@ class _FusedMLP(torch.autograd.Function):
                 n *= s
             grads.append(d_flat[off:off + n].view(shp))
             off += n
-        return (None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
-def fused_mlp_rays(rays_o, rays_d, z_vals, precision: str, packed: torch.Tensor, params: Sequence[torch.Tensor]):
+def fused_mlp_rays(rays_o, rays_d, z_vals, precision: str, packed: torch.Tensor, params: Sequence[torch.Tensor],
+                   viewdirs: bool = True):
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-    return _FusedMLP.apply("rays", rays_o, rays_d, z_vals, precision, packed, need_grad, *params)
+    return _FusedMLP.apply("rays", rays_o, rays_d, z_vals, precision, packed, need_grad, viewdirs, *params)
 
 
-def fused_mlp_encoded(x_pts, x_views, precision: str, packed: torch.Tensor, params: Sequence[torch.Tensor]):
+def fused_mlp_encoded(x_pts, x_views, precision: str, packed: torch.Tensor, params: Sequence[torch.Tensor],
+                      viewdirs: bool = True):
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-    return _FusedMLP.apply("encoded", x_pts, x_views, None, precision, packed, need_grad, *params)
+    return _FusedMLP.apply("encoded", x_pts, x_views, None, precision, packed, need_grad, viewdirs, *params)
 
 
 # ---------------------------------------------------------------------------

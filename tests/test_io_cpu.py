@@ -93,7 +93,14 @@ def test_checkpoint_wire_format(tmp_path):
     C.save_checkpoint(p2, epoch=0, global_step=1, args={"use_viewdirs": False, "use_hierarchical": False}, H=4, W=4,
                       focal=5.0, model_coarse=nv, optimizer=torch.optim.Adam(nv.parameters()))
     m1, m2, pe, pv, cfg = C.build_models(C.load_checkpoint(p2), device="cpu")
-    assert m2 is None and pv is None and not m1.use_viewdirs and cfg["precision"] == "fp32"
+    # ... which the fused 16-bit kernels cover; other depths / widths run in the fp32 validation mode
+    assert m2 is None and pv is None and not m1.use_viewdirs and cfg["precision"] == "bf16"
+    small = NeRF(D=4, W=64, skips=[2], input_ch_views=0, use_viewdirs=False, precision="fp32")
+    p3 = str(tmp_path / "small.pth")
+    C.save_checkpoint(p3, epoch=0, global_step=1, args={"use_viewdirs": False, "use_hierarchical": False, "net_depth": 4,
+                                                        "net_width": 64}, H=4, W=4, focal=5.0, model_coarse=small,
+                      optimizer=torch.optim.Adam(small.parameters()))
+    assert C.build_models(C.load_checkpoint(p3), device="cpu")[4]["precision"] == "fp32"
     torch.save({"something": 1}, str(tmp_path / "other.pth"))
     with pytest.raises(ValueError):
         C.load_checkpoint(str(tmp_path / "other.pth"))
