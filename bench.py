@@ -83,6 +83,8 @@ def parse():
                     help="the timed region of --steps steps is run this many times; the median region is reported")
     ap.add_argument("--big-batch", type=int, default=4096,
                     help="rays per GPU of the second training measurement (the data-parallel configuration's batch); 0 = skip")
+    ap.add_argument("--no-joint", action="store_true",
+                    help="keep the per-network pack and weight-gradient launches in the single-process step (A/B switch)")
     ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
     return ap.parse_args()
 
@@ -293,7 +295,7 @@ def train_leg(args, n, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_
     rays_o, rays_d = synthetic_rays(n, device, seed=rank)
     target = torch.rand(n, 3, generator=torch.Generator().manual_seed(1000 + rank)).to(device)
     mk = lambda graph: TrainStep(mc, mf, pe, pv, opt, n, near=2.0, far=6.0, N_samples_coarse=64, N_samples_fine=128,
-                                 world_size=world, use_graph=graph)
+                                 world_size=world, use_graph=graph, joint=not args.no_joint)
     step_fn = mk(not args.no_graph)
     # the batch sits in the step's own input buffers, where a loader's gather kernel writes it
     # (Trainer.train_step), so a step issues no input copies

@@ -161,6 +161,8 @@ int nerf_mse_pair(int64_t n_elements, const float *a, const float *b, const floa
  * d_params has NERF_MLP_NPARAMS_NOVIEW entries, and x_views may be NULL. */
 #define NERF_MLP_NPARAMS_NOVIEW 494084
 #define NERF_ARCH_NOVIEW 0x100
+/* networks one multi-network call (nerf_mlp_pack_multi, nerf_mlp_bwd_weights_multi) can take */
+#define NERF_WGRAD_MAX_NETS 2
 
 /* bytes of the packed-weight buffer (forward + transposed streams + biases) */
 int64_t nerf_mlp_packed_bytes(void);
@@ -170,6 +172,10 @@ int64_t nerf_mlp_packed_bytes(void);
  * nerf_mlp_fwd_encoded and the backward, NERF_PACK_INFER for nerf_mlp_fwd without `saved`, or both. */
 enum { NERF_PACK_TRAIN = 1, NERF_PACK_INFER = 2, NERF_PACK_NOVIEW = 4 /* params describe the network without view directions */ };
 int nerf_mlp_pack(const float *params, int precision, int streams, void *packed, void *stream);
+/* The same for up to NERF_WGRAD_MAX_NETS networks in one launch (the coarse and the fine network after an
+ * optimizer step): HOST arrays of n_nets parameter pointers, stream selectors and packed buffers. */
+int nerf_mlp_pack_multi(int n_nets, const float *const *params, int precision, const int *streams,
+                        void *const *packed, void *stream);
 
 /* bytes of activations the training forward saves per sample (for nerf_mlp_bwd) */
 int64_t nerf_mlp_saved_bytes(int64_t n_samples);
@@ -249,6 +255,28 @@ int nerf_mlp_bwd(int64_t M, const float *d_raw, const void *packed, int precisio
                  const float *grad_scale, void *workspace, int64_t workspace_bytes, float *d_params,
                  void *stream);
 
+/* Weight gradients of up to NERF_WGRAD_MAX_NETS networks in one launch sequence -- the second half of
+ * loss.backward() (scripts/train_nerf.py:334-335) for the coarse and the fine network together: one
+ * contraction kernel over all their GEMMs, one reduction, one launch for the factored gradients.  Each
+ * GEMM is then split over half as many workgroups as in nerf_mlp_bwd_weights, which halves the partial
+ * sums written and read.  nets: HOST array; per network the arguments of nerf_mlp_bwd_weights (M >= 1; all
+ * networks share the operand type, the architecture flag may differ).  partial:
+ * nerf_mlp_bwd_weights_multi_bytes(n_nets, nets) bytes, 256-byte aligned.  Results are bit-identical from
+ * call to call (fixed summation order), not to those of separate nerf_mlp_bwd_weights calls (the sample
+ * axis is cut differently). */
+typedef struct {
+    int64_t M;               /* samples */
+    const void *packed;      /* nerf_mlp_pack output of the network */
+    const void *saved;       /* activations kept by nerf_mlp_fwd */
+    const void *dz;          /* written by nerf_mlp_bwd_data */
+    int precision;           /* NERF_PREC_* | NERF_ARCH_* */
+    const float *grad_scale; /* nullable, as in nerf_mlp_bwd_weights */
+    float *d_params;         /* [NERF_MLP_NPARAMS] or [NERF_MLP_NPARAMS_NOVIEW] */
+} nerf_wgrad_net_t;
+int64_t nerf_mlp_bwd_weights_multi_bytes(int n_nets, const nerf_wgrad_net_t *nets);
+int nerf_mlp_bwd_weights_multi(int n_nets, const nerf_wgrad_net_t *nets, void *partial, int64_t partial_bytes,
+                               void *stream);
+
 /* The two halves of nerf_mlp_bwd as separate calls (same kernels), for callers that want to
  * time or overlap them: the backward-data chain writes every layer's dZ (16 bit,
  * nerf_mlp_dz_bytes(M) bytes); the weight-gradient pass contracts dZ with the saved activations
@@ -269,8 +297,9 @@ int nerf_adam_step(int64_t n, float *params, const float *grads, float *exp_avg,
 
 /* Same update with the hyper-parameters in device memory, so that the call can be captured in a
  * HIP graph and replayed while lr changes: state = device float[8] = {lr, beta1, beta2, eps,
- * grad_scale, step, scratch, scratch}.  The call first advances state[5] (the step count, starting
- * from 0) and then applies the update for that step. */
+ * grad_scale, step, ticket, scratch}.  The call applies the update of step state[5] + 1 and leaves
+ * state[5] advanced by one (it starts from 0); state[6] must be 0 before the first call and is 0 again
+ * after every call (a workgroup counter). */
 int nerf_adam_step_dev(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
                        float *state, void *stream);
 

@@ -36,6 +36,9 @@ _SIGS = {
     "nerf_sort_rows": (c_int, [c_int64, c_int, P, c_int, P, P, P]),
     "nerf_mlp_packed_bytes": (c_int64, []),
     "nerf_mlp_pack": (c_int, [P, c_int, c_int, P, P]),
+    "nerf_mlp_pack_multi": (c_int, [c_int, P, c_int, P, P, P]),
+    "nerf_mlp_bwd_weights_multi_bytes": (c_int64, [c_int, P]),
+    "nerf_mlp_bwd_weights_multi": (c_int, [c_int, P, P, c_int64, P]),
     "nerf_mlp_saved_bytes": (c_int64, [c_int64]),
     "nerf_mlp_bwd_workspace_bytes": (c_int64, [c_int64]),
     "nerf_mlp_fwd": (c_int, [c_int64, c_int, P, P, P, P, c_int, P, P, P]),
@@ -61,6 +64,15 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.argtypes = _args
 
 SYMBOLS = tuple(_SIGS)
+
+
+class WgradNet(ctypes.Structure):
+    """nerf_wgrad_net_t of include/nerf_hip.h: one network of a multi-network weight-gradient call."""
+    _fields_ = [("M", c_int64), ("packed", c_void_p), ("saved", c_void_p), ("dz", c_void_p), ("precision", c_int),
+                ("grad_scale", c_void_p), ("d_params", c_void_p)]
+
+
+WGRAD_MAX_NETS = 2
 
 
 class Fp32Layer(ctypes.Structure):

@@ -84,59 +84,79 @@ __host__ __device__ constexpr int total_cost(const ArchTab& t) { int c = 0; for 
 
 constexpr int WGRAD_TARGET_JOBS = 256;     // one workgroup per CU
 
-// The whole job -- every GEMM over every wave tile, laid end to end on one line measured in cost --
-// is cut into WGRAD_TARGET_JOBS pieces of equal cost; workgroup p owns piece p.  A piece that crosses
-// the end of a GEMM continues with the first wave tiles of the next one, so a workgroup runs one to
-// three GEMM segments in turn and all workgroups end together whatever the GEMMs' sizes.  Inside
-// GEMM g a piece boundary at cost b falls on wave tile floor((b - start of g) / cost of g).
-__host__ __device__ inline int64_t piece_bound(const ArchTab& t, int64_t n_wt, int p) {
-    return (int64_t)p * n_wt * total_cost(t) / WGRAD_TARGET_JOBS;
+// One launch computes the weight gradients of up to MAX_NETS networks (the coarse and the fine network of a
+// training step): their GEMMs form one list, "virtual GEMM" v = net * NGEMM + g.  With two networks each
+// GEMM is split over half as many workgroups as in a launch of its own, so half as many partial blocks are
+// written and summed.
+constexpr int MAX_NETS = NERF_WGRAD_MAX_NETS;
+constexpr int NVG = MAX_NETS * NGEMM;
+struct NetSet {
+    int n_nets;
+    int view[MAX_NETS];        // 1: full network, 0: without view directions
+    int64_t n_wt[MAX_NETS];    // wave tiles (32 samples) of each network
+};
+__host__ __device__ inline const ArchTab& tab_of(const NetSet& s, int net) { return s.view[net] ? TAB_VIEW : TAB_NOVIEW; }
+
+// The whole job -- every GEMM of every network over all its wave tiles, laid end to end on one line measured
+// in cost -- is cut into WGRAD_TARGET_JOBS pieces of equal cost; workgroup p owns piece p.  A piece that
+// crosses the end of a GEMM continues with the first wave tiles of the next one, so a workgroup runs one to
+// three GEMM segments in turn and all workgroups end together whatever the GEMMs' sizes.  Inside a GEMM
+// a piece boundary at cost b falls on wave tile floor((b - start of the GEMM) / cost of the GEMM).
+__host__ __device__ inline int64_t line_total(const NetSet& s) {
+    int64_t c = 0;
+    for (int n = 0; n < s.n_nets; ++n) c += s.n_wt[n] * total_cost(tab_of(s, n));
+    return c;
 }
-__host__ __device__ inline int64_t bound_to_wt(const ArchTab& t, int64_t n_wt, int g, int64_t b) {
+__host__ __device__ inline int64_t piece_bound(const NetSet& s, int p) {
+    return (int64_t)p * line_total(s) / WGRAD_TARGET_JOBS;
+}
+__host__ __device__ inline int64_t bound_to_wt(const NetSet& s, int net, int g, int64_t b) {
+    int64_t start = 0;
+    for (int n = 0; n < net; ++n) start += s.n_wt[n] * total_cost(tab_of(s, n));
+    const ArchTab& t = tab_of(s, net);
     int before = 0;
     for (int i = 0; i < g; ++i) before += t.cost[i];
-    if (b < n_wt * before) return 0;
-    const int64_t w = (b - n_wt * before) / t.cost[g];
-    return w > n_wt ? n_wt : w;
+    start += s.n_wt[net] * before;
+    if (b < start) return 0;
+    const int64_t w = (b - start) / t.cost[g];
+    return w > s.n_wt[net] ? s.n_wt[net] : w;
 }
-// wave tiles [wt0, wt1) of GEMM g that belong to piece p (empty when wt1 <= wt0)
-__host__ __device__ inline void piece_segment(const ArchTab& t, int64_t n_wt, int g, int p, int64_t& wt0, int64_t& wt1) {
-    wt0 = bound_to_wt(t, n_wt, g, piece_bound(t, n_wt, p));
-    wt1 = bound_to_wt(t, n_wt, g, piece_bound(t, n_wt, p + 1));
+// wave tiles [wt0, wt1) of GEMM g of network `net` that belong to piece p (empty when wt1 <= wt0)
+__host__ __device__ inline void piece_segment(const NetSet& s, int net, int g, int p, int64_t& wt0, int64_t& wt1) {
+    wt0 = bound_to_wt(s, net, g, piece_bound(s, p));
+    wt1 = bound_to_wt(s, net, g, piece_bound(s, p + 1));
 }
 
 struct JobTable {
-    int splits[NGEMM];       // pieces that hold a segment of each GEMM = partial blocks of that GEMM
-    int piece0[NGEMM];       // the first of them; a GEMM's pieces are consecutive
-    int64_t part_off[NGEMM]; // float offset of GEMM g's first partial block in the partial buffer
+    int splits[NVG];       // pieces that hold a segment of each GEMM = partial blocks of that GEMM
+    int piece0[NVG];       // the first of them; a GEMM's pieces are consecutive
+    int64_t part_off[NVG]; // float offset of the GEMM's first partial block in the partial buffer
 };
 
-static JobTable make_jobs(const ArchTab& t, int64_t n_wt) {
+static JobTable make_jobs(const NetSet& s, int64_t* total_floats) {
     JobTable j;
     int64_t off = 0;
-    for (int g = 0; g < NGEMM; ++g) {
-        j.splits[g] = 0; j.piece0[g] = 0; j.part_off[g] = off;
-        if (g >= t.ngemm) continue;
+    for (int v = 0; v < NVG; ++v) {
+        const int net = v / NGEMM, g = v % NGEMM;
+        j.splits[v] = 0; j.piece0[v] = 0; j.part_off[v] = off;
+        if (net >= s.n_nets || g >= tab_of(s, net).ngemm) continue;
         // first and last piece with wave tiles of this GEMM; with very few wave tiles a piece in between
         // can be empty: it then writes a zero block, so that the GEMM's blocks stay one range
         int first = -1, last = -1;
         for (int p = 0; p < WGRAD_TARGET_JOBS; ++p) {
             int64_t a, b;
-            piece_segment(t, n_wt, g, p, a, b);
+            piece_segment(s, net, g, p, a, b);
             if (b > a) {
                 if (first < 0) first = p;
                 last = p;
             }
         }
-        j.piece0[g] = first;
-        j.splits[g] = last - first + 1;
-        off += (int64_t)j.splits[g] * gemm_out_floats(t, g);
+        j.piece0[v] = first;
+        j.splits[v] = last - first + 1;
+        off += (int64_t)j.splits[v] * gemm_out_floats(tab_of(s, net), g);
     }
+    *total_floats = off;
     return j;
-}
-static int64_t partial_floats(const ArchTab& t, const JobTable& j) {
-    const int g = t.ngemm - 1;
-    return j.part_off[g] + (int64_t)j.splits[g] * gemm_out_floats(t, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,9 +375,9 @@ constexpr int WG_DMA_AUX = NERF_WG_DMA_AUX;    // cache policy bits of the strea
 constexpr int WG_LDS_BYTES = WG_STAGES * WG_STAGE_BYTES;
 
 struct WgradArgs {
-    int64_t n_wt;
-    const char* saved;
-    const char* dz;
+    NetSet nets;
+    const char* saved[MAX_NETS];
+    const char* dz[MAX_NETS];
     float* partial;
     JobTable jobs;
 #ifdef NERF_WG_STAMP
@@ -434,8 +454,8 @@ __device__ __forceinline__ float frag_sum(const s16x8& f) {
 // NSUB wave tiles are staged and contracted per step (GEMMs with few units would otherwise keep too few
 // bytes in flight to cover the memory latency).
 template <int PREC, int A_NKS, int B_NKS, int WR, int WC, int TI, int TJ, int NSUB = 1>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& tab, const int g, char* lds, const int split,
-                                           const int64_t wt0, const int64_t wt1) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& tab, const int net, const int g, char* lds,
+                                           const int split, const int64_t wt0, const int64_t wt1) {
     typedef typename Prec<PREC>::frag frag;
     static_assert(WR * WC <= 8 && WR * TI * 2 >= A_NKS && WC * TJ * 2 == B_NKS, "wave grid must cover the block");
     const int lane = threadIdx.x & 63;
@@ -455,10 +475,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
     const int my_units = (STAGE_UNITS - wave + 7) >> 3;       // 0..5
     // the four operand runs: base of wave tile 0, bytes per wave tile, first unit of the run in the stage
     const int a1n = gd.a_nks, b1n = gd.b_nks;
-    const char* a1_src = a.dz + (size_t)dz_ks0(gd.a_layer) * a.n_wt * 1024;
-    const char* a2_src = a.dz + (size_t)dz_ks0(gd.a2_layer) * a.n_wt * 1024;
-    const char* b1_src = a.saved + (size_t)saved_ks0(gd.b_tensor) * a.n_wt * 1024;
-    const char* b2_src = a.saved + (size_t)saved_ks0(gd.b2_tensor) * a.n_wt * 1024;
+    const int64_t n_wt = a.nets.n_wt[net];
+    const char* a1_src = a.dz[net] + (size_t)dz_ks0(gd.a_layer) * n_wt * 1024;
+    const char* a2_src = a.dz[net] + (size_t)dz_ks0(gd.a2_layer) * n_wt * 1024;
+    const char* b1_src = a.saved[net] + (size_t)saved_ks0(gd.b_tensor) * n_wt * 1024;
+    const char* b2_src = a.saved[net] + (size_t)saved_ks0(gd.b2_tensor) * n_wt * 1024;
     const size_t a1_stride = (size_t)DZ_KS[gd.a_layer] * 1024, a2_stride = (size_t)DZ_KS[gd.a2_layer] * 1024;
     const size_t b1_stride = (size_t)SAVED_KS[gd.b_tensor] * 1024, b2_stride = (size_t)SAVED_KS[gd.b2_tensor] * 1024;
 
@@ -592,7 +613,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
     // partial block: [R][C] row-major then R bias sums
     if (!active) return;
     constexpr int R = A_NKS * 16, C = B_NKS * 16;
-    float* out = a.partial + a.jobs.part_off[g] + (int64_t)split * gemm_out_floats(tab, g);
+    float* out = a.partial + a.jobs.part_off[net * NGEMM + g] + (int64_t)split * gemm_out_floats(tab, g);
     const int col_l = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -613,30 +634,34 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
     }
 }
 
-template <int PREC, bool VIEW>
+template <int PREC>
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[WG_LDS_BYTES];
 #ifdef NERF_WG_STAMP
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    const ArchTab& tab = arch_tab<VIEW>();
     const int p = blockIdx.x;
     bool ran = false;
-    for (int g = 0; g < tab.ngemm; ++g) {
-        const int split = p - a.jobs.piece0[g];
-        if (split < 0 || split >= a.jobs.splits[g]) continue;          // workgroup-uniform
-        int64_t wt0, wt1;
-        piece_segment(tab, a.n_wt, g, p, wt0, wt1);
-        // the previous segment's last LDS reads (other waves) before this one's first copies
-        if (ran) __syncthreads();
-        ran = true;
-        // shape dispatch: <A units, B units, wave grid, tiles per wave, wave tiles per step>
-        if (g == 0) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, tab, g, lds, split, wt0, wt1);
-        else if (g == 5) wgrad_body<PREC, 16, 20, 4, 2, 2, 5>(a, tab, g, lds, split, wt0, wt1);
-        else if (g == 8 && VIEW) wgrad_body<PREC, 9, 18, 2, 3, 3, 3>(a, tab, g, lds, split, wt0, wt1);
-        else if (g == 8) wgrad_body<PREC, 1, 16, 1, 8, 1, 1, 2>(a, tab, g, lds, split, wt0, wt1);
-        else if (g == 9) wgrad_body<PREC, 1, 8, 1, 4, 1, 1, 4>(a, tab, g, lds, split, wt0, wt1);
-        else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, tab, g, lds, split, wt0, wt1);
+    for (int net = 0; net < a.nets.n_nets; ++net) {
+        const bool view = a.nets.view[net];
+        const ArchTab& tab = tab_of(a.nets, net);
+        for (int g = 0; g < tab.ngemm; ++g) {
+            const int v = net * NGEMM + g;
+            const int split = p - a.jobs.piece0[v];
+            if (split < 0 || split >= a.jobs.splits[v]) continue;          // workgroup-uniform
+            int64_t wt0, wt1;
+            piece_segment(a.nets, net, g, p, wt0, wt1);
+            // the previous segment's last LDS reads (other waves) before this one's first copies
+            if (ran) __syncthreads();
+            ran = true;
+            // shape dispatch: <A units, B units, wave grid, tiles per wave, wave tiles per step>
+            if (g == 0) wgrad_body<PREC, 16, 4, 8, 1, 1, 2>(a, tab, net, g, lds, split, wt0, wt1);
+            else if (g == 5) wgrad_body<PREC, 16, 20, 4, 2, 2, 5>(a, tab, net, g, lds, split, wt0, wt1);
+            else if (g == 8 && view) wgrad_body<PREC, 9, 18, 2, 3, 3, 3>(a, tab, net, g, lds, split, wt0, wt1);
+            else if (g == 8) wgrad_body<PREC, 1, 16, 1, 8, 1, 1, 2>(a, tab, net, g, lds, split, wt0, wt1);
+            else if (g == 9) wgrad_body<PREC, 1, 8, 1, 4, 1, 1, 4>(a, tab, net, g, lds, split, wt0, wt1);
+            else wgrad_body<PREC, 16, 16, 4, 2, 2, 4>(a, tab, net, g, lds, split, wt0, wt1);
+        }
     }
 #ifdef NERF_WG_STAMP
     if (a.stamps && threadIdx.x == 0) {
@@ -663,17 +688,20 @@ __device__ __forceinline__ int pe_pos(int f, int L) {
 }
 
 struct ReduceArgs {
+    NetSet nets;
     const float* partial;
-    float* d_params;
-    float* prod;            // [128][256]: P = dZ9^T H7 in feature order, for mlp_post_kernel
-    const float* scale;     // nullable: divide by *scale
+    float* d_params[MAX_NETS];
+    float* prod[MAX_NETS];            // [128][256]: P = dZ9^T H7 in feature order, for mlp_post_kernel
+    const float* scale[MAX_NETS];     // nullable: divide by *scale
+    const float* post[MAX_NETS];      // the network's W_f, b_f, W_r0[:, :256] table (packed weights)
     JobTable jobs;
 };
 constexpr int PROD_FLOATS = 128 * 256;
 
-__device__ __forceinline__ float sum_partials(const ReduceArgs& a, const ArchTab& tab, int g, int idx) {
-    const float* p = a.partial + a.jobs.part_off[g] + idx;
-    const int n = a.jobs.splits[g];
+__device__ __forceinline__ float sum_partials(const ReduceArgs& a, const ArchTab& tab, int net, int g, int idx) {
+    const int v = net * NGEMM + g;
+    const float* p = a.partial + a.jobs.part_off[v] + idx;
+    const int n = a.jobs.splits[v];
     const int stride = gemm_out_floats(tab, g);
     float s = 0.f;
 #pragma unroll 8
@@ -681,16 +709,22 @@ __device__ __forceinline__ float sum_partials(const ReduceArgs& a, const ArchTab
     return s;
 }
 
-template <bool VIEW>
+// outputs of one network: its parameters and, for the full network, the product P
+__host__ __device__ inline int reduce_outputs(int view) { return view ? N_PARAMS + PROD_FLOATS : N_PARAMS_NV; }
+
 __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
-    const ArchTab& tab = arch_tab<VIEW>();
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (VIEW ? N_PARAMS + PROD_FLOATS : N_PARAMS_NV)) return;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int net = 0;
+    while (net < a.nets.n_nets && e >= reduce_outputs(a.nets.view[net])) { e -= reduce_outputs(a.nets.view[net]); ++net; }
+    if (net >= a.nets.n_nets) return;
+    const bool VIEW = a.nets.view[net];
+    const ArchTab& tab = tab_of(a.nets, net);
+    const float* scale = a.scale[net];
     if (VIEW && e >= N_PARAMS) {                        // the product P, handed to mlp_post_kernel
         const int k = (e - N_PARAMS) >> 8, i = (e - N_PARAMS) & 255;
-        float v = sum_partials(a, tab, 8, hidden_pos(k) * (gemm_b_nks(tab, 8) * 16) + hidden_pos(i));
-        if (a.scale) v = v / *a.scale;
-        a.prod[e - N_PARAMS] = v;
+        float v = sum_partials(a, tab, net, 8, hidden_pos(k) * (gemm_b_nks(tab, 8) * 16) + hidden_pos(i));
+        if (scale) v = v / *scale;
+        a.prod[net][e - N_PARAMS] = v;
         return;
     }
     int g, row, col = -1;      // col < 0: bias element
@@ -733,9 +767,9 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
     }
     const int R = gemm_a_nks(tab, g) * 16, C = gemm_b_nks(tab, g) * 16;
     const int idx = col >= 0 ? row * C + col : R * C + row;
-    float v = sum_partials(a, tab, g, idx);
-    if (a.scale) v = v / *a.scale;
-    a.d_params[e] = v;
+    float v = sum_partials(a, tab, net, g, idx);
+    if (scale) v = v / *scale;
+    a.d_params[net][e] = v;
 }
 
 // The factored gradients (mlp_common.hpp, saved-tensor layout): with P = dZ9^T H7 [128][256] and
@@ -747,8 +781,12 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const ReduceArgs a) {
 // address of the other.  The loops are unrolled so that sixteen terms' loads are in flight together
 // (a thread's chain of 128 or 256 dependent load-then-fma steps is otherwise latency-bound).
 constexpr int POST_OUTPUTS = 256 * 256 + 256 + 128 * 256;
-__global__ __launch_bounds__(256) void mlp_post_kernel(const float* __restrict__ prod, const float* __restrict__ post,
-                                                       float* __restrict__ d_params) {
+__global__ __launch_bounds__(256) void mlp_post_kernel(const ReduceArgs a) {
+    const int net = blockIdx.y;
+    if (!a.nets.view[net]) return;           // the network without view directions has no factored gradients
+    const float* __restrict__ prod = a.prod[net];
+    const float* __restrict__ post = a.post[net];
+    float* __restrict__ d_params = a.d_params[net];
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const float* wft = post + POST_WF;       // [in][out]
     const float* bf = post + POST_BF;
@@ -783,12 +821,39 @@ using namespace nerf::mlp;
 
 static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+static int net_set(int n_nets, const nerf_wgrad_net_t* nets, NetSet* out, int* prec) {
+    NERF_REQUIRE(nets, NERF_E_NULL);
+    NERF_REQUIRE(n_nets >= 1 && n_nets <= MAX_NETS, NERF_E_SHAPE);
+    NetSet s{};
+    s.n_nets = n_nets;
+    for (int n = 0; n < n_nets; ++n) {
+        NERF_REQUIRE(nets[n].M >= 1, NERF_E_SHAPE);
+        NERF_REQUIRE(nerf_prec_ok(nets[n].precision), NERF_E_DTYPE);
+        const int p = nets[n].precision & ~NERF_ARCH_NOVIEW;
+        if (n == 0) *prec = p;
+        NERF_REQUIRE(p == *prec, NERF_E_DTYPE);            // one operand type per launch
+        s.view[n] = !(nets[n].precision & NERF_ARCH_NOVIEW);
+        s.n_wt[n] = (nets[n].M + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
+    }
+    *out = s;
+    return NERF_OK;
+}
+
+extern "C" int64_t nerf_mlp_bwd_weights_multi_bytes(int n_nets, const nerf_wgrad_net_t* nets) {
+    NetSet s; int prec = 0;
+    if (net_set(n_nets, nets, &s, &prec) != NERF_OK) return -1;
+    int64_t floats = 0;
+    make_jobs(s, &floats);
+    return round_up(floats * 4, 256) + (int64_t)n_nets * PROD_FLOATS * 4;     // partial blocks, then the products P
+}
+
 extern "C" int64_t nerf_mlp_partial_bytes(int64_t n_samples) {
-    const int64_t n_wt = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
     // enough for either architecture
-    const int64_t a = partial_floats(TAB_VIEW, make_jobs(TAB_VIEW, n_wt > 0 ? n_wt : 1));
-    const int64_t b = partial_floats(TAB_NOVIEW, make_jobs(TAB_NOVIEW, n_wt > 0 ? n_wt : 1));
-    return round_up((a > b ? a : b) * 4, 256) + (int64_t)PROD_FLOATS * 4;     // partial blocks, then the product P
+    nerf_wgrad_net_t a{}, b{};
+    a.M = b.M = n_samples > 0 ? n_samples : 1;
+    a.precision = NERF_PREC_BF16; b.precision = NERF_PREC_BF16 | NERF_ARCH_NOVIEW;
+    const int64_t x = nerf_mlp_bwd_weights_multi_bytes(1, &a), y = nerf_mlp_bwd_weights_multi_bytes(1, &b);
+    return x > y ? x : y;
 }
 
 extern "C" int64_t nerf_mlp_bwd_workspace_bytes(int64_t n_samples) {
@@ -807,18 +872,6 @@ extern "C" int64_t nerf_mlp_dz_bytes(int64_t n_samples) {
     return round_up(n_tiles * 8 * (int64_t)DZ_UNITS * 1024, 256);
 }
 
-// launch K<PREC, VIEW> for the runtime (precision, view)
-#define NERF_LAUNCH_ARCH(K, GRID, BLOCK, ST, ARG)                                                              \
-    do {                                                                                                       \
-        if (prec == NERF_PREC_BF16) {                                                                          \
-            if (view) hipLaunchKernelGGL((K<NERF_PREC_BF16, true>), GRID, BLOCK, 0, ST, ARG);                  \
-            else hipLaunchKernelGGL((K<NERF_PREC_BF16, false>), GRID, BLOCK, 0, ST, ARG);                      \
-        } else {                                                                                               \
-            if (view) hipLaunchKernelGGL((K<NERF_PREC_FP16, true>), GRID, BLOCK, 0, ST, ARG);                  \
-            else hipLaunchKernelGGL((K<NERF_PREC_FP16, false>), GRID, BLOCK, 0, ST, ARG);                      \
-        }                                                                                                      \
-    } while (0)
-
 extern "C" int nerf_mlp_bwd_data(int64_t M, const float* d_raw, const void* packed, int precision,
                                  const void* saved, const float* grad_scale, void* dz, void* stream) {
     int rc = check_bwd_common(M, precision);
@@ -835,7 +888,64 @@ extern "C" int nerf_mlp_bwd_data(int64_t M, const float* d_raw, const void* pack
     b.dz = (char*)dz; b.scale = grad_scale;
     const dim3 gb((unsigned)(n_tiles < 256 ? n_tiles : 256)), tb(CHAIN_THREADS);
     hipStream_t st = (hipStream_t)stream;
-    NERF_LAUNCH_ARCH(mlp_dgrad_kernel, gb, tb, st, b);
+    if (prec == NERF_PREC_BF16) {
+        if (view) hipLaunchKernelGGL((mlp_dgrad_kernel<NERF_PREC_BF16, true>), gb, tb, 0, st, b);
+        else hipLaunchKernelGGL((mlp_dgrad_kernel<NERF_PREC_BF16, false>), gb, tb, 0, st, b);
+    } else {
+        if (view) hipLaunchKernelGGL((mlp_dgrad_kernel<NERF_PREC_FP16, true>), gb, tb, 0, st, b);
+        else hipLaunchKernelGGL((mlp_dgrad_kernel<NERF_PREC_FP16, false>), gb, tb, 0, st, b);
+    }
+    return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_bwd_weights_multi(int n_nets, const nerf_wgrad_net_t* nets, void* partial, int64_t partial_bytes,
+                                          void* stream) {
+    NetSet s; int prec = 0;
+    int rc = net_set(n_nets, nets, &s, &prec);
+    if (rc) return rc;
+    NERF_REQUIRE(partial, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(partial, 256), NERF_E_ALIGN);
+    for (int n = 0; n < n_nets; ++n) {
+        NERF_REQUIRE(nets[n].packed && nets[n].saved && nets[n].dz && nets[n].d_params, NERF_E_NULL);
+        NERF_REQUIRE(nerf_aligned(nets[n].packed, 256) && nerf_aligned(nets[n].saved, 256) && nerf_aligned(nets[n].dz, 256),
+                     NERF_E_ALIGN);
+    }
+    int64_t floats = 0;
+    const JobTable jobs = make_jobs(s, &floats);
+    const int64_t prod_off = round_up(floats * 4, 256);
+    NERF_REQUIRE(partial_bytes >= prod_off + (int64_t)n_nets * PROD_FLOATS * 4, NERF_E_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+
+    WgradArgs w{};
+    w.nets = s; w.partial = (float*)partial; w.jobs = jobs;
+    for (int n = 0; n < n_nets; ++n) { w.saved[n] = (const char*)nets[n].saved; w.dz[n] = (const char*)nets[n].dz; }
+#ifdef NERF_WG_STAMP
+    {   // stamps go behind everything the library uses of the partial buffer, when the caller left room
+        const int64_t used = prod_off + (int64_t)n_nets * PROD_FLOATS * 4;
+        w.stamps = partial_bytes >= used + 16 * 1024 ? reinterpret_cast<unsigned long long*>((char*)partial + used) : nullptr;
+    }
+#endif
+    const dim3 gw((unsigned)WGRAD_TARGET_JOBS), tw(512);
+    if (prec == NERF_PREC_BF16) hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_BF16>, gw, tw, 0, st, w);
+    else hipLaunchKernelGGL(mlp_wgrad_kernel<NERF_PREC_FP16>, gw, tw, 0, st, w);
+    rc = nerf_launch_status();
+    if (rc) return rc;
+
+    ReduceArgs r{};
+    r.nets = s; r.partial = (const float*)partial; r.jobs = jobs;
+    int64_t outputs = 0;
+    bool any_view = false;
+    for (int n = 0; n < n_nets; ++n) {
+        r.d_params[n] = nets[n].d_params; r.scale[n] = nets[n].grad_scale;
+        r.prod[n] = reinterpret_cast<float*>((char*)partial + prod_off) + (int64_t)n * PROD_FLOATS;
+        r.post[n] = reinterpret_cast<const float*>((const char*)nets[n].packed + PACK_POST_OFF);
+        outputs += reduce_outputs(s.view[n]);
+        any_view |= s.view[n] != 0;
+    }
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((outputs + 255) / 256)), dim3(256), 0, st, r);
+    rc = nerf_launch_status();
+    if (rc || !any_view) return rc;
+    hipLaunchKernelGGL(mlp_post_kernel, dim3((POST_OUTPUTS + 255) / 256, n_nets), dim3(256), 0, st, r);
     return nerf_launch_status();
 }
 
@@ -845,48 +955,15 @@ extern "C" int nerf_mlp_bwd_weights(int64_t M, const void* packed, const void* s
     int rc = check_bwd_common(M, precision);
     if (rc) return rc;
     NERF_REQUIRE(d_params, NERF_E_NULL);
-    const bool view = !(precision & NERF_ARCH_NOVIEW);
-    const int prec = precision & ~NERF_ARCH_NOVIEW;
-    const ArchTab& tab = view ? TAB_VIEW : TAB_NOVIEW;
-    hipStream_t st = (hipStream_t)stream;
     if (M == 0) {
-        hipError_t e = hipMemsetAsync(d_params, 0, sizeof(float) * (view ? N_PARAMS : N_PARAMS_NV), st);
+        const bool view = !(precision & NERF_ARCH_NOVIEW);
+        hipError_t e = hipMemsetAsync(d_params, 0, sizeof(float) * (view ? N_PARAMS : N_PARAMS_NV), (hipStream_t)stream);
         return e == hipSuccess ? NERF_OK : (int)e;
     }
-    NERF_REQUIRE(packed && saved && dz && partial, NERF_E_NULL);
-    NERF_REQUIRE(nerf_aligned(packed, 256) && nerf_aligned(saved, 256) && nerf_aligned(dz, 256) &&
-                     nerf_aligned(partial, 256), NERF_E_ALIGN);
-    const int64_t n_wt = (M + TILE_SAMPLES - 1) / TILE_SAMPLES * 8;
-    const JobTable jobs = make_jobs(tab, n_wt);
-    const int64_t prod_off = round_up(partial_floats(tab, jobs) * 4, 256);
-    NERF_REQUIRE(partial_bytes >= prod_off + (int64_t)PROD_FLOATS * 4, NERF_E_WORKSPACE);
-
-    WgradArgs w{};
-    w.n_wt = n_wt; w.saved = (const char*)saved; w.dz = (const char*)dz; w.partial = (float*)partial; w.jobs = jobs;
-#ifdef NERF_WG_STAMP
-    {   // stamps go behind everything the library uses of the partial buffer, when the caller left room
-        const int64_t used = prod_off + (int64_t)PROD_FLOATS * 4;
-        w.stamps = partial_bytes >= used + 16 * 1024 ? reinterpret_cast<unsigned long long*>((char*)partial + used) : nullptr;
-    }
-#endif
-    const dim3 gw((unsigned)WGRAD_TARGET_JOBS), tw(512);
-    NERF_LAUNCH_ARCH(mlp_wgrad_kernel, gw, tw, st, w);
-    rc = nerf_launch_status();
-    if (rc) return rc;
-
-    ReduceArgs r{};
-    r.partial = (const float*)partial; r.d_params = d_params; r.scale = grad_scale; r.jobs = jobs;
-    r.prod = reinterpret_cast<float*>((char*)partial + prod_off);
-    if (!view) {
-        hipLaunchKernelGGL(mlp_reduce_kernel<false>, dim3((N_PARAMS_NV + 255) / 256), dim3(256), 0, st, r);
-        return nerf_launch_status();
-    }
-    hipLaunchKernelGGL(mlp_reduce_kernel<true>, dim3((N_PARAMS + PROD_FLOATS + 255) / 256), dim3(256), 0, st, r);
-    rc = nerf_launch_status();
-    if (rc) return rc;
-    hipLaunchKernelGGL(mlp_post_kernel, dim3((POST_OUTPUTS + 255) / 256), dim3(256), 0, st, r.prod,
-                       reinterpret_cast<const float*>((const char*)packed + PACK_POST_OFF), d_params);
-    return nerf_launch_status();
+    nerf_wgrad_net_t net{};
+    net.M = M; net.packed = packed; net.saved = saved; net.dz = dz; net.precision = precision;
+    net.grad_scale = grad_scale; net.d_params = d_params;
+    return nerf_mlp_bwd_weights_multi(1, &net, partial, partial_bytes, stream);
 }
 
 extern "C" int nerf_mlp_bwd(int64_t M, const float* d_raw, const void* packed, int precision, const void* saved,

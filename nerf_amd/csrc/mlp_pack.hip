@@ -108,8 +108,18 @@ __device__ __forceinline__ float nv_out_weight(const float* __restrict__ P, int 
     return row < 4 ? P[OFF_WO + row * 256 + slot] : 0.0f;
 }
 
+struct PackArgs {
+    const float* params[NERF_WGRAD_MAX_NETS];
+    char* out[NERF_WGRAD_MAX_NETS];
+    int streams[NERF_WGRAD_MAX_NETS];
+};
+
+// blockIdx.y = network
 template <int PREC>
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, char* __restrict__ out, int streams) {
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
+    const float* __restrict__ P = args.params[blockIdx.y];
+    char* __restrict__ out = args.out[blockIdx.y];
+    const int streams = args.streams[blockIdx.y];
     const bool noview = streams & NERF_PACK_NOVIEW;
     typedef typename Prec<PREC>::elem T;
     typedef typename Prec<PREC>::frag frag;
@@ -230,18 +240,28 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ P, 
 
 extern "C" int64_t nerf_mlp_packed_bytes(void) { return nerf::mlp::PACK_BYTES; }
 
-extern "C" int nerf_mlp_pack(const float* params, int precision, int streams, void* packed, void* stream) {
-    NERF_REQUIRE(params && packed, NERF_E_NULL);
-    if (precision & NERF_ARCH_NOVIEW) { precision &= ~NERF_ARCH_NOVIEW; streams |= NERF_PACK_NOVIEW; }
-    NERF_REQUIRE((streams & (NERF_PACK_TRAIN | NERF_PACK_INFER)) != 0 && (streams & ~(NERF_PACK_TRAIN | NERF_PACK_INFER | NERF_PACK_NOVIEW)) == 0, NERF_E_SHAPE);
-    NERF_REQUIRE(nerf_aligned(packed, 256), NERF_E_ALIGN);
+extern "C" int nerf_mlp_pack_multi(int n_nets, const float* const* params, int precision, const int* streams,
+                                   void* const* packed, void* stream) {
+    NERF_REQUIRE(params && streams && packed, NERF_E_NULL);
+    NERF_REQUIRE(n_nets >= 1 && n_nets <= NERF_WGRAD_MAX_NETS, NERF_E_SHAPE);
     NERF_REQUIRE(precision == NERF_PREC_BF16 || precision == NERF_PREC_FP16, NERF_E_DTYPE);
-    const dim3 grid(1024), block(256);
+    nerf::mlp::PackArgs a{};
+    for (int n = 0; n < n_nets; ++n) {
+        NERF_REQUIRE(params[n] && packed[n], NERF_E_NULL);
+        NERF_REQUIRE((streams[n] & (NERF_PACK_TRAIN | NERF_PACK_INFER)) != 0 &&
+                     (streams[n] & ~(NERF_PACK_TRAIN | NERF_PACK_INFER | NERF_PACK_NOVIEW)) == 0, NERF_E_SHAPE);
+        NERF_REQUIRE(nerf_aligned(packed[n], 256), NERF_E_ALIGN);
+        a.params[n] = params[n]; a.out[n] = (char*)packed[n]; a.streams[n] = streams[n];
+    }
+    const dim3 grid(1024, n_nets), block(256);
     if (precision == NERF_PREC_BF16)
-        hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_BF16>, grid, block, 0, (hipStream_t)stream, params,
-                           (char*)packed, streams);
+        hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_BF16>, grid, block, 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_FP16>, grid, block, 0, (hipStream_t)stream, params,
-                           (char*)packed, streams);
+        hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_FP16>, grid, block, 0, (hipStream_t)stream, a);
     return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_pack(const float* params, int precision, int streams, void* packed, void* stream) {
+    if (precision & NERF_ARCH_NOVIEW) { precision &= ~NERF_ARCH_NOVIEW; streams |= NERF_PACK_NOVIEW; }
+    return nerf_mlp_pack_multi(1, &params, precision, &streams, &packed, stream);
 }

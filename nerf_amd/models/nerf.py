@@ -97,6 +97,7 @@ class NeRF(nn.Module):
         self._pack_key = None
         self._packed = None
         self._fp32_prog = None
+        self._external_pack = None
 
     # -- kernel plumbing ------------------------------------------------------------------
     def kernel_supported(self) -> bool:
@@ -140,6 +141,8 @@ class NeRF(nn.Module):
         from step to step, which HIP-graph capture of a training step relies on); under no_grad the
         packed buffer is cached and re-made only when a parameter was modified or replaced."""
         self._require_supported()
+        if self._external_pack is not None:         # a training step packed all its networks in one launch
+            return self._external_pack
         ps = self.ordered_params()
         training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
         key = None if training else (self.precision,) + tuple((p.data_ptr(), p._version) for p in ps)

@@ -445,6 +445,22 @@ class _FusedMLP(torch.autograd.Function):
             with _timed("mlp_bwd_data", dev, M):
                 check(lib.nerf_mlp_bwd_data(M, _p(d_raw), _p(ctx.packed), ctx.prec, _p(ctx.saved_acts), _p(scale),
                                             _p(dz), st), "nerf_mlp_bwd_data")
+            sink = None if GRAD_SINKS is None else GRAD_SINKS.get(ctx.packed.data_ptr())
+            if sink is not None and DEFERRED_WGRAD is None:
+                # the weight gradients go straight into the caller's buffer (a slice of an optimizer's bucket)
+                part_bytes = int(lib.nerf_mlp_partial_bytes(M))
+                part = torch.empty((part_bytes,), dtype=torch.uint8, device=dev)
+                with _timed("mlp_bwd_weights", dev, M):
+                    check(lib.nerf_mlp_bwd_weights(M, _p(ctx.packed), _p(ctx.saved_acts), _p(dz), ctx.prec, _p(scale), _p(part),
+                                                   part_bytes, _p(sink), st), "nerf_mlp_bwd_weights")
+                ctx.saved_acts = None
+                return (None,) * (8 + len(ctx.shapes))
+            if DEFERRED_WGRAD is not None:
+                # the caller runs the weight gradients of all its networks in one launch (mlp_bwd_weights_multi)
+                DEFERRED_WGRAD.append(dict(M=M, packed=ctx.packed, saved=ctx.saved_acts, dz=dz, prec=ctx.prec, scale=scale,
+                                           n_params=ctx.n_params, shapes=ctx.shapes))
+                ctx.saved_acts = None
+                return (None,) * (8 + len(ctx.shapes))
             with _timed("mlp_bwd_weights", dev, M):
                 check(lib.nerf_mlp_bwd_weights(M, _p(ctx.packed), _p(ctx.saved_acts), _p(dz), ctx.prec, _p(scale), _p(part),
                                                part_bytes, _p(d_flat), st), "nerf_mlp_bwd_weights")
@@ -458,6 +474,63 @@ class _FusedMLP(torch.autograd.Function):
             grads.append(d_flat[off:off + n].view(shp))
             off += n
         return (None, None, None, None, None, None, None, None, *grads)
+
+
+# When this is a list, _FusedMLP.backward stops after the backward-data pass and appends what the weight-gradient
+# pass needs; mlp_bwd_weights_multi() then serves all entries in one launch sequence.
+DEFERRED_WGRAD = None
+# {data_ptr of a network's packed weights: flat fp32 tensor}: _FusedMLP.backward writes that network's weight
+# gradients there and returns no gradients to autograd.
+GRAD_SINKS = None
+
+
+def mlp_bwd_weights_multi(entries, d_params: Sequence[torch.Tensor]) -> None:
+    """Weight gradients of the deferred networks ``entries`` (at most two) into the flat fp32 tensors ``d_params``
+    (one per entry, e.g. slices of an optimizer's gradient bucket)."""
+    if not entries:
+        return
+    if len(entries) > _C.WGRAD_MAX_NETS or len(entries) != len(d_params):
+        raise ValueError("mlp_bwd_weights_multi takes at most two networks and one gradient tensor per network")
+    dev = entries[0]["dz"].device
+    nets = (_C.WgradNet * len(entries))()
+    for n, (e, d) in enumerate(zip(entries, d_params)):
+        if not (d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.numel() == e["n_params"]):
+            raise RuntimeError(f"gradient tensor {n} must be a contiguous fp32 GPU tensor of {e['n_params']} elements")
+        nets[n].M, nets[n].packed, nets[n].saved, nets[n].dz = e["M"], e["packed"].data_ptr(), e["saved"].data_ptr(), e["dz"].data_ptr()
+        nets[n].precision = e["prec"]
+        nets[n].grad_scale = None if e["scale"] is None else e["scale"].data_ptr()
+        nets[n].d_params = d.data_ptr()
+    nbytes = int(lib.nerf_mlp_bwd_weights_multi_bytes(len(entries), ctypes.cast(nets, ctypes.c_void_p)))
+    if nbytes < 0:
+        raise ValueError("mlp_bwd_weights_multi: the networks must share one operand type")
+    part = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("mlp_bwd_weights", dev, sum(e["M"] for e in entries)):
+        check(lib.nerf_mlp_bwd_weights_multi(len(entries), ctypes.cast(nets, ctypes.c_void_p), _p(part), nbytes, _stream(dev)),
+              "nerf_mlp_bwd_weights_multi")
+
+
+def mlp_pack_multi(flat_params: Sequence[torch.Tensor], precision: str, streams: int, viewdirs: Sequence[bool],
+                   out: Optional[Sequence[torch.Tensor]] = None):
+    """``mlp_pack`` for up to two networks in one launch; ``out``: packed buffers to overwrite."""
+    n = len(flat_params)
+    if not 1 <= n <= _C.WGRAD_MAX_NETS or len(viewdirs) != n:
+        raise ValueError("mlp_pack_multi takes one or two networks")
+    flats = [_gpu_f32(f, "flat_params") for f in flat_params]
+    for f, v in zip(flats, viewdirs):
+        want = _C.NERF_MLP_NPARAMS if v else _C.NERF_MLP_NPARAMS_NOVIEW
+        if f.numel() != want:
+            raise ValueError(f"expected {want} parameters, got {f.numel()}")
+    dev = flats[0].device
+    nb = int(lib.nerf_mlp_packed_bytes())
+    if out is None:
+        out = [torch.empty((nb,), dtype=torch.uint8, device=dev) for _ in range(n)]
+    P = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flats])
+    S = (ctypes.c_int * n)(*[int(streams) | (0 if v else 4) for v in viewdirs])
+    O_ = (ctypes.c_void_p * n)(*[o.data_ptr() for o in out])
+    with torch.cuda.device(dev):
+        check(lib.nerf_mlp_pack_multi(n, ctypes.cast(P, ctypes.c_void_p), _C.PREC[precision], ctypes.cast(S, ctypes.c_void_p),
+                                      ctypes.cast(O_, ctypes.c_void_p), _stream(dev)), "nerf_mlp_pack_multi")
+    return list(out)
 
 
 def fused_mlp_rays(rays_o, rays_d, z_vals, precision: str, packed: torch.Tensor, params: Sequence[torch.Tensor],

@@ -35,13 +35,15 @@ class TrainStep:
     def __init__(self, model_coarse, model_fine, embed_fn_pts, embed_fn_views, optimizer: FlatAdam, n_rays: int,
                  near: float = 2.0, far: float = 6.0, N_samples_coarse: int = 64, N_samples_fine: int = 128,
                  lindisp: bool = False, white_bkgd: bool = False, world_size: int = 1, use_graph: bool = True,
-                 external_uniforms: bool = False):
+                 external_uniforms: bool = False, joint: bool = True):
         """``model_fine=None`` is the coarse-only run of train_nerf.py:303 (no ``--use_hierarchical``);
         ``embed_fn_views=None`` (or a model built with ``use_viewdirs=False``) the run without
         ``--use_viewdirs`` (train_nerf.py:79, :181-184).  With ``external_uniforms`` the step reads its
         uniform draws from the static buffer ``self.uniforms`` instead of generating them (parity tests
         inject the reference's draws there): [n, Nc] jitter of the coarse pass, then [n, Nf] inverse-CDF
-        uniforms and [n, Nc+Nf] jitter of the fine pass, flattened and concatenated."""
+        uniforms and [n, Nc+Nf] jitter of the fine pass, flattened and concatenated.  ``joint=False`` keeps
+        the per-network launches even where the merged ones apply (``_joint_layout``); the two orders of
+        summation give weight gradients that differ in the last bits."""
         self.mc, self.mf, self.pe, self.pv, self.opt = model_coarse, model_fine, embed_fn_pts, embed_fn_views, optimizer
         self.near, self.far, self.nc, self.nf = near, far, N_samples_coarse, N_samples_fine
         self.lindisp, self.white = lindisp, white_bkgd
@@ -68,6 +70,38 @@ class TrainStep:
         if self._fine is not None and not (self._fine[0] == 0 or self._fine[1] == n_par):
             self._fine = None          # (the coarse parameters must be one range too)
         self.opt.device_state()[4] = 1.0 / world_size        # gradients are summed over ranks, then averaged
+        self._joint = self._joint_layout() if joint else None
+        if self._joint is not None:
+            nb = int(ops.lib.nerf_mlp_packed_bytes())
+            self._packed_bufs = [torch.empty((nb,), dtype=torch.uint8, device=dev) for _ in self._joint]
+
+    def _joint_layout(self):
+        """[(model, first float, last float)] when the step can pack the networks in one launch and compute
+        their weight gradients in one launch sequence straight into the optimizer's bucket: a single process
+        (data-parallel training keeps the two backward passes apart to overlap the first all-reduce), fused
+        16-bit networks of one precision, each network's parameters one range of the bucket in state_dict
+        order.  Else None: the networks are packed and differentiated one by one."""
+        from .models.nerf import NeRF
+        models = [self.mc] + ([self.mf] if self.hier else [])
+        if self.world != 1 or not all(isinstance(m, NeRF) and m.fused() for m in models):
+            return None
+        if len({m.precision for m in models}) != 1:
+            return None
+        ids = [id(p) for p in self.opt.params]
+        layout = []
+        for m in models:
+            ps = m.ordered_params()
+            try:
+                first = ids.index(id(ps[0]))
+            except ValueError:
+                return None
+            if ids[first:first + len(ps)] != [id(p) for p in ps]:
+                return None
+            lo = sum(self.opt.sizes[:first])
+            layout.append((m, lo, lo + sum(self.opt.sizes[first:first + len(ps)])))
+        if sum(hi - lo for _, lo, hi in layout) != self.opt.flat.numel():
+            return None                 # the optimizer holds parameters of something else as well
+        return layout
 
     # the step body: losses of train_nerf.py:299, :330-331; gradients into the optimizer's flat bucket
     def _forward(self):
@@ -96,12 +130,54 @@ class TrainStep:
         return coarse["rgb_map"], fine["rgb_map"], d_coarse, d_fine
 
     def _forward_backward(self):
+        if self._joint is not None:
+            return self._forward_backward_joint()
         rgb_c, rgb_f, d_c, d_f = self._forward()
         if rgb_f is None:
             torch.autograd.backward([rgb_c], [d_c])
         else:
             torch.autograd.backward([rgb_c, rgb_f], [d_c, d_f])
         self.opt.gather_grads()
+
+    # Above this many bytes of saved activations + dZ of the smaller network the weight gradients of all
+    # networks run as one launch sequence.  Below it that network's backward-data output is still in the
+    # 256 MB last-level cache when its own weight-gradient launch follows at once, which is worth more than
+    # the partial sums a merged launch saves (measured: 1024 rays per step 11 us slower merged, 4096 rays
+    # 50 us faster).
+    MERGE_WGRAD_BYTES = 1 << 30
+
+    def _forward_backward_joint(self):
+        """The same step with the launches that exist once per network merged: one pack launch for all weight
+        streams, weight gradients written straight into the optimizer's gradient bucket (no concatenation),
+        and for large batches one weight-gradient contraction, one reduction and one launch for the factored
+        gradients for all networks."""
+        models = [m for m, _, _ in self._joint]
+        sinks = [self.opt.flat_grad[lo:hi] for _, lo, hi in self._joint]
+        ops.mlp_pack_multi([self.opt.flat[lo:hi] for _, lo, hi in self._joint], models[0].precision, ops.PACK_TRAIN,
+                           [m.use_viewdirs for m in models], out=self._packed_bufs)
+        smallest = self.rays_o.shape[0] * self.nc * 9344          # bytes per sample: 4832 saved + 4416 dZ + masks read
+        merge = len(models) > 1 and smallest > self.MERGE_WGRAD_BYTES
+        try:
+            for m, buf in zip(models, self._packed_bufs):
+                m._external_pack = buf
+            rgb_c, rgb_f, d_c, d_f = self._forward()
+            if merge:
+                ops.DEFERRED_WGRAD = []
+            else:
+                ops.GRAD_SINKS = {buf.data_ptr(): g for buf, g in zip(self._packed_bufs, sinks)}
+            if rgb_f is None:
+                torch.autograd.backward([rgb_c], [d_c])
+            else:
+                torch.autograd.backward([rgb_c, rgb_f], [d_c, d_f])
+            entries = ops.DEFERRED_WGRAD
+        finally:
+            ops.DEFERRED_WGRAD = None
+            ops.GRAD_SINKS = None
+            for m in models:
+                m._external_pack = None
+        if merge:
+            by_pack = {e["packed"].data_ptr(): e for e in entries}
+            ops.mlp_bwd_weights_multi([by_pack[buf.data_ptr()] for buf in self._packed_bufs], sinks)
 
     # the same, split where the data-parallel collectives go
     def _forward_backward_fine(self):

@@ -29,7 +29,10 @@ for N, S in ((1024, 64), (1024, 192), (4096, 192)):
     raw = torch.empty(N, S, 4, device=DEV)
     saved = torch.empty(int(lib.nerf_mlp_saved_bytes(M)), dtype=torch.uint8, device=DEV)
     dz = torch.empty(int(lib.nerf_mlp_dz_bytes(M)), dtype=torch.uint8, device=DEV)
-    pb = int(lib.nerf_mlp_partial_bytes(M))
+    import ctypes
+    one = (_C.WgradNet * 1)()
+    one[0].M, one[0].precision = M, _C.PREC[prec]
+    pb = int(lib.nerf_mlp_bwd_weights_multi_bytes(1, ctypes.cast(one, ctypes.c_void_p)))      # stamps follow what the library uses
     part = torch.zeros(pb + 64 * 1024, dtype=torch.uint8, device=DEV)
     d_raw = torch.randn(N, S, 4, device=DEV) * 1e-3
     d_flat = torch.empty(_C.NERF_MLP_NPARAMS, device=DEV)

@@ -26,7 +26,9 @@ def run_steps(world, rank, mode, n=256, steps=3):
     opt = FlatAdam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
     ro, rd = synthetic_rays(n, dev, seed=0)
     tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(7 if (mode == "split" and rank == 1) else 0)).to(dev)
-    step = TrainStep(mc, mf, pe, pv, opt, n, world_size=world, use_graph=True)
+    # the single-process reference keeps the per-network launches of the data-parallel step: merged launches
+    # cut the sample axis differently and agree only to rounding
+    step = TrainStep(mc, mf, pe, pv, opt, n, world_size=world, use_graph=True, joint=False)
     step.prepare()
     torch.manual_seed(123)                  # the same jitter draws on every rank and in the single-process run
     losses = [step(ro, rd, tgt, lr=5e-4).item() for _ in range(steps)]
