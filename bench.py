@@ -200,6 +200,16 @@ def whole_frame_kernels(device):
                 n, S, raw.data_ptr(), z.data_ptr(), 0, g_rgb.data_ptr(), None, None, None, None, None,
                 d_raw.data_ptr(), st), "nerf_composite_bwd"), n * (36 * S + 12))
             del raw, z, g_rgb, d_raw
+        # the fp32-operand validation kernel (v_mfma_f32_32x32x2_f32) on the encoded inputs of 1024 rays x 256 samples
+        from nerf_amd.models.nerf import NeRF
+        from nerf_amd.utils.synthetic import seed_parameters_
+        m32 = seed_parameters_(NeRF(precision="fp32").to(device), 0)
+        xp, xv = torch.randn(262144, 63, device=device), torch.randn(262144, 27, device=device)
+        r32 = rate(lambda: m32(xp, xv), 0, iters=3)
+        tf = 262144 * MLP_FWD_FLOP / r32["avg_us"] / 1e6
+        out["mlp_fwd_fp32_262144_samples"] = {"avg_us": r32["avg_us"], "TFLOP/s": round(tf, 1), "peak_TFLOP/s": 157.3,
+                                              "frac_of_fp32_mfma_peak": round(tf / 157.3, 4)}
+        del m32, xp, xv
         c2w = torch.eye(4, device=device)[:3].contiguous()
         out["get_rays_800x800"] = rate(lambda: ops.get_rays(800, 800, 1111.0, c2w), n * 24, iters=20)
         # 983 MB written per launch: four times the 256 MB infinity cache, so this is the HBM rate

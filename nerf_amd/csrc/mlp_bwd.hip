@@ -184,6 +184,10 @@ __device__ __forceinline__ void store_unit_frag(char* base, int ks0, int nks, in
     *reinterpret_cast<typename Prec<PREC>::frag*>(base + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
     return;
 #endif
+#ifdef NERF_ABL_PLAIN_STORE      // timing experiment: default cache policy instead of non-temporal
+    *reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
+    return;
+#endif
     __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
 }
 

@@ -112,6 +112,10 @@ __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t
     *reinterpret_cast<typename Prec<PREC>::frag*>(saved + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
     return;
 #endif
+#ifdef NERF_ABL_PLAIN_STORE      // timing experiment: default cache policy instead of non-temporal
+    *reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
+    return;
+#endif
     __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
 }
 

@@ -139,45 +139,29 @@ class TrainStep:
             torch.autograd.backward([rgb_c, rgb_f], [d_c, d_f])
         self.opt.gather_grads()
 
-    # Above this many bytes of saved activations + dZ of the smaller network the weight gradients of all
-    # networks run as one launch sequence.  Below it that network's backward-data output is still in the
-    # 256 MB last-level cache when its own weight-gradient launch follows at once, which is worth more than
-    # the partial sums a merged launch saves (measured: 1024 rays per step 11 us slower merged, 4096 rays
-    # 50 us faster).
-    MERGE_WGRAD_BYTES = 1 << 30
-
     def _forward_backward_joint(self):
-        """The same step with the launches that exist once per network merged: one pack launch for all weight
-        streams, weight gradients written straight into the optimizer's gradient bucket (no concatenation),
-        and for large batches one weight-gradient contraction, one reduction and one launch for the factored
-        gradients for all networks."""
+        """The same step with one pack launch for all weight streams and the weight gradients written straight
+        into the optimizer's gradient bucket (no concatenation).  The weight-gradient launches stay one per
+        network: a merged launch (ops.mlp_bwd_weights_multi) halves the partial sums, but each network's
+        backward-data output is still partly in the last-level cache when its own weight-gradient launch
+        follows at once, and on one box the two orders measured equal within noise at 1024 and 4096 rays."""
         models = [m for m, _, _ in self._joint]
         sinks = [self.opt.flat_grad[lo:hi] for _, lo, hi in self._joint]
         ops.mlp_pack_multi([self.opt.flat[lo:hi] for _, lo, hi in self._joint], models[0].precision, ops.PACK_TRAIN,
                            [m.use_viewdirs for m in models], out=self._packed_bufs)
-        smallest = self.rays_o.shape[0] * self.nc * 9344          # bytes per sample: 4832 saved + 4416 dZ + masks read
-        merge = len(models) > 1 and smallest > self.MERGE_WGRAD_BYTES
         try:
             for m, buf in zip(models, self._packed_bufs):
                 m._external_pack = buf
             rgb_c, rgb_f, d_c, d_f = self._forward()
-            if merge:
-                ops.DEFERRED_WGRAD = []
-            else:
-                ops.GRAD_SINKS = {buf.data_ptr(): g for buf, g in zip(self._packed_bufs, sinks)}
+            ops.GRAD_SINKS = {buf.data_ptr(): g for buf, g in zip(self._packed_bufs, sinks)}
             if rgb_f is None:
                 torch.autograd.backward([rgb_c], [d_c])
             else:
                 torch.autograd.backward([rgb_c, rgb_f], [d_c, d_f])
-            entries = ops.DEFERRED_WGRAD
         finally:
-            ops.DEFERRED_WGRAD = None
             ops.GRAD_SINKS = None
             for m in models:
                 m._external_pack = None
-        if merge:
-            by_pack = {e["packed"].data_ptr(): e for e in entries}
-            ops.mlp_bwd_weights_multi([by_pack[buf.data_ptr()] for buf in self._packed_bufs], sinks)
 
     # the same, split where the data-parallel collectives go
     def _forward_backward_fine(self):

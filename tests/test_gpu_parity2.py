@@ -230,3 +230,43 @@ def test_packed_weight_cache_follows_graph_replayed_training(amd, use_graph):
     with torch.no_grad():
         r_fresh = amd.render_hierarchical(mc2, mf2, pe, pv, ro, rd, 2.0, 6.0, 64, 128)[1]["rgb_map"]
     assert torch.equal(r2, r_fresh)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_merged_weight_gradient_call_equals_separate_calls(precision):
+    """nerf_mlp_bwd_weights_multi (both networks of a step in one launch sequence, straight into two slices of one
+    bucket) against one nerf_mlp_bwd_weights call per network: the sample axis is cut differently, so the sums
+    agree to fp32 rounding (1e-5 of the largest gradient), and the merged call is bit-reproducible."""
+    from nerf_amd import ops, _C
+    lib, _p = ops.lib, ops._p
+    P = ops._prec(precision, True)
+    st = torch.cuda.current_stream().cuda_stream
+    entries, separate = [], []
+    for seed, (N, S) in enumerate(((96, 64), (96, 192))):
+        m = amd_model(O.init_params(seed), precision)
+        packed = m.packed_weights()
+        M = N * S
+        ro, rd = O.synthetic_rays(N, seed=seed)
+        z = torch.sort(torch.rand(N, S, generator=torch.Generator().manual_seed(seed)) * 4 + 2, dim=-1).values
+        raw = torch.empty(N, S, 4, device=DEV)
+        saved = torch.empty(int(lib.nerf_mlp_saved_bytes(M)), dtype=torch.uint8, device=DEV)
+        dz = torch.empty(int(lib.nerf_mlp_dz_bytes(M)), dtype=torch.uint8, device=DEV)
+        d_raw = (torch.randn(N, S, 4, generator=torch.Generator().manual_seed(10 + seed)) * 1e-3).to(DEV)
+        ro, rd, z = ro.to(DEV).contiguous(), rd.to(DEV).contiguous(), z.to(DEV).contiguous()
+        ops.check(lib.nerf_mlp_fwd(N, S, _p(ro), _p(rd), _p(z), _p(packed), P, _p(raw), _p(saved), st), "fwd")
+        scale = torch.full((1,), 1024.0, device=DEV) if precision == "fp16" else None
+        ops.check(lib.nerf_mlp_bwd_data(M, _p(d_raw), _p(packed), P, _p(saved), _p(scale), _p(dz), st), "dgrad")
+        part = torch.empty(int(lib.nerf_mlp_partial_bytes(M)), dtype=torch.uint8, device=DEV)
+        d = torch.empty(_C.NERF_MLP_NPARAMS, device=DEV)
+        ops.check(lib.nerf_mlp_bwd_weights(M, _p(packed), _p(saved), _p(dz), P, _p(scale), _p(part), part.numel(), _p(d), st), "wgrad")
+        separate.append(d)
+        entries.append(dict(M=M, packed=packed, saved=saved, dz=dz, prec=P, scale=scale, n_params=_C.NERF_MLP_NPARAMS))
+    bucket = torch.zeros(2 * _C.NERF_MLP_NPARAMS, device=DEV)
+    sinks = [bucket[:_C.NERF_MLP_NPARAMS], bucket[_C.NERF_MLP_NPARAMS:]]
+    ops.mlp_bwd_weights_multi(entries, sinks)
+    first = bucket.clone()
+    for a, b in zip(sinks, separate):
+        assert maxabs(a, b) < 1e-5 * b.abs().max().item()
+    bucket.zero_()
+    ops.mlp_bwd_weights_multi(entries, sinks)
+    assert torch.equal(bucket, first)
