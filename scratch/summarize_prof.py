@@ -16,7 +16,7 @@ cmd = open(os.path.join(src, "command.txt")).read().strip()
 
 # bench.py's kernel names -> device kernel names
 BENCH_NAMES = {"mlp_bwd_weights": "mlp_wgrad_kernel", "mlp_bwd_data": "mlp_dgrad_kernel",
-               "mlp_fwd_train": "mlp_fwd_kernel<0, true, false>", "mlp_fwd": "mlp_fwd16_kernel<0>"}
+               "mlp_fwd_train": "mlp_fwd_kernel<0, true, false, true>", "mlp_fwd": "mlp_fwd16_kernel<0, true>"}
 
 
 def short(n):
@@ -35,7 +35,7 @@ def find(sub, name):
 rows = list(csv.DictReader(open(find("trace", "kernel_stats.csv"))))
 with open(os.path.join(dst, "kernel_stats.txt"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}\n")
-    f.write("# (3 warm-up + 10 timed graph-replayed training steps, 3 eager steps, then the frame renders, four camera-path frames and the whole-frame kernel launches)\n")
+    f.write("# (graph capture, 3 warm-up + 10 timed graph-replayed training steps at 1024 rays, 3 eager steps, then the frame renders, four camera-path frames and the whole-frame kernel launches)\n")
     f.write(f"{'kernel':92s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}\n")
     for r in rows[:30]:
         f.write(f"{short(r['Name']):92s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.1f} "
