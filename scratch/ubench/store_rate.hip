@@ -1,0 +1,52 @@
+// Write-rate ceiling of the training forward's store pattern: 256 workgroups x 8 waves, each wave writing 1 KiB
+// units (16 bytes per lane, non-temporal), tensor-major like the saved activations (a wave's 16 units of a layer
+// are contiguous, layers are n_wt * 16 KiB apart).
+//   mode 0: stores back to back              mode 1: two stores, then about 1000 idle cycles (a tile of MFMAs)
+//   mode 2: as 1 with plain (cached) stores  mode 3: as 1, but all of a pass's units contiguous per wave (144 KiB)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int LAYERS = 9, UNITS = 16;
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k(char* out, int passes, long n_wt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i32x4 v = {lane, wave, (int)blockIdx.x, 7};
+    for (int p = 0; p < passes; ++p) {
+        const long wt = ((long)p * gridDim.x + blockIdx.x) * 8 + wave;
+        for (int l = 0; l < LAYERS; ++l) {
+            for (int u = 0; u < UNITS; u += 2) {
+                char* a = MODE == 3 ? out + ((wt * LAYERS + l) * UNITS + u) * 1024 + lane * 16
+                                    : out + (((long)l * n_wt + wt) * UNITS + u) * 1024 + lane * 16;
+                if (MODE == 2) { *(i32x4*)a = v; *(i32x4*)(a + 1024) = v; }
+                else { __builtin_nontemporal_store(v, (i32x4*)a); __builtin_nontemporal_store(v, (i32x4*)(a + 1024)); }
+                if (MODE != 0) { __builtin_amdgcn_s_sleep(8); __builtin_amdgcn_s_sleep(8); }
+                v[3] += 1;
+            }
+        }
+    }
+}
+
+int main() {
+    const int passes = 3, grid = 256;
+    const long n_wt = (long)passes * grid * 8;
+    const size_t bytes = (size_t)n_wt * LAYERS * UNITS * 1024;
+    char* buf; hipMalloc(&buf, bytes);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 4; ++mode) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            for (int i = 0; i < 10; ++i) {
+                if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
+                if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
+                if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep) printf("mode %d: %.1f us per launch, %.2f GB -> %.0f GB/s\n", mode, ms * 100, bytes / 1e9, bytes / (ms / 10 * 1e-3) / 1e9);
+        }
+    }
+    return 0;
+}
