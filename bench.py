@@ -15,7 +15,7 @@ Rank 0 prints one JSON line.  `value` = rays processed by all ranks / wall time 
 median of --repeats timed regions of exactly --steps steps each.  The line also carries the same step at
 4096 rays per GPU (the data-parallel configuration's batch) and, for N > 1, a row-sharded 800x800 frame render
 with its all_gather and a frame-sharded slice of the 120-pose camera path.
-The timed steps replay the step from HIP graphs (a 1024-ray step is 28 short launches; issued from
+The timed steps replay the step from HIP graphs (a 1024-ray step is 25 short launches; issued from
 Python the host would be the bottleneck).  `roofline` describes the kernel with the largest share of
 GPU time in the step; its duration comes from HIP events recorded on the launch stream around every
 launch while the same step is issued eagerly right after the timed region.  `cpu_baseline` times the CPU oracle
@@ -455,6 +455,31 @@ def main():
         # scaling curve exists; the headline value stays at the same per-GPU batch for every N
         big = train_leg(args, args.big_batch, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_ranks, 0,
                         step0=leg["next_step"])
+    default_flags = None
+    if world == 1 and not args.no_render:
+        # the reference script's default flags (train_nerf.py:62, :79): coarse network only, no view directions
+        from nerf_amd.models.nerf import NeRF, PositionalEncoder
+        from nerf_amd.optim import FlatAdam
+        from nerf_amd.train import TrainStep
+        from nerf_amd.utils.synthetic import seed_parameters_, synthetic_rays
+        m0 = seed_parameters_(NeRF(input_ch_views=0, use_viewdirs=False, precision=args.precision).to(device), 0)
+        o0 = FlatAdam(list(m0.parameters()), lr=5e-4)
+        s0 = TrainStep(m0, None, PositionalEncoder(3, 10).to(device), None, o0, n, N_samples_coarse=64,
+                       use_graph=not args.no_graph)
+        ro0, rd0 = synthetic_rays(n, device, seed=0)
+        s0.rays_o.copy_(ro0); s0.rays_d.copy_(rd0); s0.target.copy_(torch.rand(n, 3, device=device))
+        for _ in range(args.warmup):
+            s0(s0.rays_o, s0.rays_d, s0.target, lr=5e-4)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s0(s0.rays_o, s0.rays_d, s0.target, lr=5e-4)
+        sync()
+        d0 = (time.perf_counter() - t0) / args.steps
+        default_flags = {"workload": "training step with the reference script's default flags: coarse network only (64 samples), "
+                                     "no view directions, %d rays, fused 16-bit kernels" % n,
+                         "ms_per_step": round(d0 * 1e3, 4), "rays_per_s": round(n / d0, 1)}
+        del s0, o0, m0
     allreduce_us = None
     if world > 1:
         # the collective on its own: the whole gradient bucket, back to back, after the timed regions
@@ -551,6 +576,8 @@ def main():
                 "ms_per_step": round(big["dt"] / args.steps * 1e3, 4), "ms_per_step_each": big["regions_ms_per_step"],
                 "step_mfma_frac": round(nb * args.steps / big["dt"] * MLP_FLOP_PER_RAY_TRAIN / (MFMA_PEAK_TFLOPS * 1e12), 4),
                 "launch_mode": "eager (%s)" % big["graph_error"] if big["graph_error"] else "as the headline"}
+        if default_flags is not None:
+            out["train_default_flags"] = default_flags
         if allreduce_us is not None:
             out["allreduce"] = {"bytes": int(opt.flat_grad.numel()) * 4, "avg_us": round(allreduce_us, 1),
                                 "note": "summing all-reduce of the whole fp32 gradient bucket of both networks, 10 back to back "

@@ -66,14 +66,15 @@ def _consecutive_view(ps) -> Optional[torch.Tensor]:
 class NeRF(nn.Module):
     """The NeRF MLP with the reference's parameters (nerf.py:126-153) and forward (nerf.py:173-209).
 
-    The fused HIP kernels implement the architecture the reference's scripts instantiate
-    (D=8, W=256, input_ch_pts=63, input_ch_views=27, skips=[4], use_viewdirs=True).
+    The fused 16-bit HIP kernels implement the two networks the reference's scripts instantiate
+    (train_nerf.py:189-200): D=8, W=256, input_ch_pts=63, skips=[4], with input_ch_views=27 and
+    use_viewdirs=True, or with use_viewdirs=False (the script default).
 
     ``precision`` selects the MFMA operand type ('bf16' or 'fp16'); accumulation is fp32.
-    ``precision='fp32'`` is the validation mode: the layers run one by one as fp32 library GEMMs
-    (rocBLAS through ``torch.nn.functional.linear``) under plain autograd; the encodings and
-    compositing around it are still the HIP kernels.  An architecture outside the fused kernels
-    (other D / W / skips / encodings) runs in that fp32 mode whatever ``precision`` says
+    ``precision='fp32'`` is the validation mode: an fp32-operand MFMA kernel evaluates the layers (any
+    depth, width up to 256, any skips; ``fp32_kernel_supported()``), its gradients come from library
+    GEMMs under autograd; the encodings and compositing around it are the same HIP kernels.  An
+    architecture outside the fused 16-bit kernels runs in that fp32 mode whatever ``precision`` says
     (``effective_precision()`` reports it).
     """
 

@@ -1,6 +1,6 @@
 """The training step of scripts/train_nerf.py:288-336 as one callable, optionally replayed from a HIP graph.
 
-A 1024-ray step is 28 short kernel launches; issued one by one from Python the host is
+A 1024-ray step is 25 short kernel launches; issued one by one from Python the host is
 the bottleneck.  ``TrainStep`` runs the same call sequence eagerly or captures it once into HIP
 graphs and replays them, with the inputs in static buffers and the optimizer's hyper-parameters in
 device memory so that the learning rate can change between replays.  A single process captures the

@@ -3,6 +3,8 @@
 // are contiguous, layers are n_wt * 16 KiB apart).
 //   mode 0: stores back to back              mode 1: two stores, then about 1000 idle cycles (a tile of MFMAs)
 //   mode 2: as 1 with plain (cached) stores  mode 3: as 1, but all of a pass's units contiguous per wave (144 KiB)
+//   mode 4: one store per ~500 idle cycles   mode 5: a layer's 16 stores in one burst, then ~8000 idle cycles
+//   mode 6: as 1, waves start staggered by wave * 128 cycles
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -13,9 +15,20 @@ template <int MODE>
 __global__ __launch_bounds__(512, 2) void k(char* out, int passes, long n_wt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     i32x4 v = {lane, wave, (int)blockIdx.x, 7};
+    if (MODE == 6) for (int q = 0; q < wave; ++q) __builtin_amdgcn_s_sleep(2);
     for (int p = 0; p < passes; ++p) {
         const long wt = ((long)p * gridDim.x + blockIdx.x) * 8 + wave;
         for (int l = 0; l < LAYERS; ++l) {
+            if (MODE == 4 || MODE == 5) {
+                for (int u = 0; u < UNITS; ++u) {
+                    char* a = out + (((long)l * n_wt + wt) * UNITS + u) * 1024 + lane * 16;
+                    __builtin_nontemporal_store(v, (i32x4*)a);
+                    if (MODE == 4) __builtin_amdgcn_s_sleep(8);
+                    v[3] += 1;
+                }
+                if (MODE == 5) for (int q = 0; q < 16; ++q) __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
             for (int u = 0; u < UNITS; u += 2) {
                 char* a = MODE == 3 ? out + ((wt * LAYERS + l) * UNITS + u) * 1024 + lane * 16
                                     : out + (((long)l * n_wt + wt) * UNITS + u) * 1024 + lane * 16;
@@ -34,7 +47,7 @@ int main() {
     const size_t bytes = (size_t)n_wt * LAYERS * UNITS * 1024;
     char* buf; hipMalloc(&buf, bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             for (int i = 0; i < 10; ++i) {
@@ -42,6 +55,9 @@ int main() {
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
                 if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
+                if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(grid), dim3(512), 0, 0, buf, passes, n_wt);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
