@@ -105,18 +105,28 @@ __global__ __launch_bounds__(256) void encode_units_kernel(int64_t M, int64_t n_
     }
 }
 
+// Stores of the kept activations.  The unit address is wave-uniform (the wave index comes from readfirstlane), so
+// the store takes the scalar-base form: base in SGPRs, the lane's byte offset in one VGPR.  A per-lane 64-bit
+// pointer per saved tensor would live through the whole pass, and a spilled one is reloaded with vmcnt(0), which
+// waits for every store of the pass.
 template <int PREC>
 __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
                                           int lane_off, const typename Prec<PREC>::frag& f) {
+    typedef typename Prec<PREC>::frag frag;
 #ifdef NERF_ABL_STORE_LOCAL      // timing experiment only: every store of a wave goes to one L2-resident KiB
-    *reinterpret_cast<typename Prec<PREC>::frag*>(saved + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
+    *reinterpret_cast<frag*>(saved + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
     return;
 #endif
+    char* unit = saved + unit_offset(ks0, nks, n_wt, wt, ks);        // wave-uniform
 #ifdef NERF_ABL_PLAIN_STORE      // timing experiment: default cache policy instead of non-temporal
-    *reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
+    *reinterpret_cast<frag*>(unit + (uint32_t)lane_off) = f;
     return;
 #endif
-    __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(saved + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
+    __builtin_nontemporal_store(f, reinterpret_cast<frag*>(unit + (uint32_t)lane_off));
+}
+// one dword per lane at byte offset lane_off4 of the wave-uniform address `base`
+__device__ __forceinline__ void save_dword(char* base, int lane_off4, uint32_t v) {
+    *reinterpret_cast<uint32_t*>(base + (uint32_t)lane_off4) = v;
 }
 
 // signs of one finished output tile (already ReLU'd and rounded: 16-bit values with a clear top bit),
@@ -161,31 +171,82 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
     const int64_t n_wt = a.n_tiles * 8;
     char* const mask_base = SAVE ? a.saved + (size_t)n_wt * SAVED_UNITS * 1024 : nullptr;
 
+    // Ray inputs of a pass (fused mode): z of this lane's sample, origin and direction of its ray.  The loads
+    // of the NEXT pass are issued two layers before the current pass ends and turned into the point encoding
+    // and the unit view direction after its last layer: at a pass boundary nothing then waits for memory (a
+    // load issued there would also wait for the pass's last stores, which the memory counter orders before it).
+    // The loads are inline asm: the compiler would wait for a load it knows about with vmcnt(0) at the first use
+    // after the chunk-entry asm, draining the weight ring and the pass's stores.  inputs_landed<N>() is the wait:
+    // N must not exceed the vector-memory operations this wave issues between the loads and the wait.
+    struct RayIn { float z, ox, oy, oz, dx, dy, dz; };
+    auto load_inputs = [&](int64_t tile2) {
+        RayIn r;
+        int64_t m2 = (tile2 * 8 + wave) * WAVE_SAMPLES + c;
+        if (m2 >= a.M) m2 = a.M - 1;                      // lanes past the end load a valid sample
+        const int64_t ray = m2 / a.S;
+        const float* zp = a.z + m2;
+        const float* o = a.rays_o + 3 * ray;
+        const float* d = a.rays_d + 3 * ray;
+#ifdef NERF_ABL_NO_INPUTS        // (timing experiment only: no input loads, constant encodings)
+        r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#else
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.z) : "v"(zp));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.ox) : "v"(o));
+        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(r.oy) : "v"(o));
+        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(r.oz) : "v"(o));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.dx) : "v"(d));
+        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(r.dy) : "v"(d));
+        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(r.dz) : "v"(d));
+#endif
+        return r;
+    };
+#define NERF_INPUTS_LANDED(R, N)                                                                               \
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(R.z), "+v"(R.ox), "+v"(R.oy), "+v"(R.oz), "+v"(R.dx), "+v"(R.dy), "+v"(R.dz) : "n"(N))
+    // raw[m] of this lane's sample, from lane half 0.  The lane id passes through an empty asm here, so that the
+    // address is formed at the store and no per-lane pointer lives (or is spilled) through the pass.
+    auto raw_store = [&](int64_t wt_now, float4 v) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int64_t mm = wt_now * WAVE_SAMPLES + (l & 31);
+        if (mm < a.M && l < 32) {
+            char* row = reinterpret_cast<char*>(a.raw) + wt_now * (WAVE_SAMPLES * 16);     // wave-uniform
+            *reinterpret_cast<float4*>(row + (uint32_t)(l * 16)) = v;
+        }
+    };
+    frag pe[PE_KS];
+    float vx = 0.f, vy = 0.f, vz = 0.f;   // unit view direction (fused mode)
+    auto use_inputs = [&](const RayIn& r, bool ok) {
+        float px = 0.f, py = 0.f, pz = 0.f;
+        vx = vy = vz = 0.f;
+        if (ok) {
+            px = __fadd_rn(r.ox, __fmul_rn(r.dx, r.z));        // nerf.py:409
+            py = __fadd_rn(r.oy, __fmul_rn(r.dy, r.z));
+            pz = __fadd_rn(r.oz, __fmul_rn(r.dz, r.z));
+            const float n = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(r.dx, r.dx), __fmul_rn(r.dy, r.dy)), __fmul_rn(r.dz, r.dz)));
+            vx = r.dx / n; vy = r.dy / n; vz = r.dz / n;       // nerf.py:417
+        }
+        encode<PREC, 10, PE_KS>(px, py, pz, h, pe);
+    };
+    if (!ENCODED && (int64_t)blockIdx.x < a.n_tiles) {
+        RayIn r = load_inputs(blockIdx.x);
+        NERF_INPUTS_LANDED(r, 0);                         // first pass only: nothing to overlap with yet
+        use_inputs(r, ((int64_t)blockIdx.x * 8 + wave) * WAVE_SAMPLES + c < a.M);
+    }
+
     for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int64_t wt = tile * 8 + wave;
-        const int64_t m = wt * WAVE_SAMPLES + c;
-        const bool valid = m < a.M;
+        const bool has_next = tile + gridDim.x < a.n_tiles;
+        RayIn next_in = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // Operations between the next pass's loads and their use: without view directions L7 (4 chunk entries of 4
+        // copies, 16 unit stores, 4 mask stores), else L9 (3 entries, 8 unit stores, 2 mask stores); the final
+        // store of raw may be skipped by a wave past the end and is not counted.
+        constexpr int YOUNGER_THAN_INPUTS = VIEW ? 3 * DMA_PER_CHUNK + 10 : 4 * DMA_PER_CHUNK + 20;
+        static_assert(fwd_block0(9) % CHUNK_BLOCKS == 0 && fwd_block0(7) % CHUNK_BLOCKS == 16, "chunk entries inside L9 / L7");
 
-        frag pe[PE_KS];
-        float vx = 0.f, vy = 0.f, vz = 0.f;   // unit view direction (fused mode)
         if (ENCODED) {
 #pragma unroll
             for (int ks = 0; ks < PE_KS; ++ks)
                 pe[ks] = *reinterpret_cast<const frag*>(a.pe_units + (wt * PE_KS + ks) * 1024 + lane_off);
-        } else {
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (valid) {
-                const int64_t ray = m / a.S;
-                const float zz = a.z[m];
-                const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
-                const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-                px = __fadd_rn(ox, __fmul_rn(dx, zz));        // nerf.py:409
-                py = __fadd_rn(oy, __fmul_rn(dy, zz));
-                pz = __fadd_rn(oz, __fmul_rn(dz, zz));
-                const float n = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-                vx = dx / n; vy = dy / n; vz = dz / n;        // nerf.py:417
-            }
-            encode<PREC, 10, PE_KS>(px, py, pz, h, pe);
         }
         if (SAVE && !ENCODED) {          // in encoded mode the units already are the saved tensors
 #pragma unroll
@@ -196,10 +257,10 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
         constexpr int SV = SAVE ? 2 : 0;     // stores per tile epilogue
         frag ha[H_KS], hb[H_KS];
         uint32_t even_bits = 0;               // sign bits of the last even tile, until its odd partner ends
-        char* const mask_wt = SAVE ? mask_base + (size_t)wt * MASK_TENSORS * 1024 + lane * 4 : nullptr;
+        char* const mask_wt = SAVE ? mask_base + (size_t)wt * MASK_TENSORS * 1024 : nullptr;       // wave-uniform
         auto save_signs = [&](int tensor, int mt, const frag& f0, const frag& f1) {
             const uint32_t bits = sign_bits<PREC>(f0, f1);
-            if (mt & 1) *reinterpret_cast<uint32_t*>(mask_wt + tensor * 1024 + (mt >> 1) * 256) = (even_bits >> 8) | bits;
+            if (mt & 1) save_dword(mask_wt + tensor * 1024 + (mt >> 1) * 256, lane * 4, (even_bits >> 8) | bits);
             else even_bits = bits;
         };
         auto hidden = [&](auto LAYER, frag* out) {
@@ -224,14 +285,18 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
         run_layer<PREC, fwd_block0(4), 8, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(4), hidden(NERF_IC(4), ha));
         run_layer<PREC, fwd_block0(5), 8, PE_KS, H_KS, SV>(ring, lds, pe, ha, NERF_BIAS(5), hidden(NERF_IC(5), hb));
         run_layer<PREC, fwd_block0(6), 8, H_KS, 0, SV>(ring, lds, hb, hb, NERF_BIAS(6), hidden(NERF_IC(6), ha));
+        if (!VIEW && !ENCODED && has_next) next_in = load_inputs(tile + gridDim.x);
         run_layer<PREC, fwd_block0(7), 8, H_KS, 0, SV>(ring, lds, ha, ha, NERF_BIAS(7), hidden(NERF_IC(7), hb));
 
         if (!VIEW) {
             // L8 of the network without view directions: output_linear -> rows 0..3 = (rgb_raw, sigma_raw)
             run_layer<PREC, fwd_block0(8), 1, H_KS, 0>(ring, lds, hb, hb, NERF_BIAS(8), [&](int, const f32x16& acc) {
-                if (valid && h == 0)
-                    reinterpret_cast<float4*>(a.raw)[m] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                raw_store(wt, make_float4(acc[0], acc[1], acc[2], acc[3]));
             });
+            if (!ENCODED) {      // unconditional, so that the encoding registers are free from L6 to here
+                NERF_INPUTS_LANDED(next_in, YOUNGER_THAN_INPUTS);
+                use_inputs(next_in, has_next && ((tile + gridDim.x) * 8 + wave) * WAVE_SAMPLES + c < a.M);
+            }
             continue;
         }
         // L8: feature_linear (no activation) -> ha, sigma_linear -> row 0 of tile 8
@@ -258,6 +323,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
             for (int ks = 0; ks < VPE_KS; ++ks)
                 save_frag<PREC>(a.saved, saved_ks0(SV_VPE), VPE_KS, n_wt, wt, ks, lane_off, vpe[ks]);
         }
+        if (!ENCODED && has_next) next_in = load_inputs(tile + gridDim.x);
         run_layer<PREC, fwd_block0(9), 4, H_KS, VPE_KS, SV>(ring, lds, ha, vpe, NERF_BIAS(9), [&](int mt, const f32x16& acc) {
             tile_to_frags<PREC, true>(acc, hb[2 * mt], hb[2 * mt + 1]);
             if (SAVE) {
@@ -269,9 +335,12 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
 
         // L10: rgb_layers.2 -> rows 0..2; output (rgb_raw, sigma_raw) per sample from lane half 0
         run_layer<PREC, fwd_block0(10), 1, G_KS, 0>(ring, lds, hb, hb, NERF_BIAS(10), [&](int, const f32x16& acc) {
-            if (valid && h == 0)
-                reinterpret_cast<float4*>(a.raw)[m] = make_float4(acc[0], acc[1], acc[2], sigma);
+            raw_store(wt, make_float4(acc[0], acc[1], acc[2], sigma));
         });
+        if (!ENCODED) {          // unconditional, so that the encoding registers are free from L6 to here
+            NERF_INPUTS_LANDED(next_in, YOUNGER_THAN_INPUTS);
+            use_inputs(next_in, has_next && ((tile + gridDim.x) * 8 + wave) * WAVE_SAMPLES + c < a.M);
+        }
 #undef NERF_BIAS
 #undef NERF_IC
     }
@@ -284,6 +353,32 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
 
 using namespace nerf::mlp;
 
+// This file is compiled three times (NERF_TU, see the Makefile): the kernels of one operand type each
+// (NERF_TU = 1: bf16, 2: fp16 -- twelve fully unrolled instantiations take minutes, the two halves build in
+// parallel), and the host entry points (NERF_TU = 0).
+#ifndef NERF_TU
+#error "compile with -DNERF_TU=0 (entry points), 1 (bf16 kernels) or 2 (fp16 kernels)"
+#endif
+namespace nerf {
+namespace mlp {
+template <int PREC>
+void launch_fwd_prec(const FwdArgs& a, bool save, bool encoded, bool view, dim3 g, dim3 b, hipStream_t st)
+#if NERF_TU == 0
+    ;
+#else
+{
+#define NERF_LAUNCH(SV, EN) do { if (view) hipLaunchKernelGGL((mlp_fwd_kernel<PREC, SV, EN, true>), g, b, 0, st, a); \
+                                 else hipLaunchKernelGGL((mlp_fwd_kernel<PREC, SV, EN, false>), g, b, 0, st, a); } while (0)
+    if (save) { if (encoded) NERF_LAUNCH(true, true); else NERF_LAUNCH(true, false); }
+    else { NERF_LAUNCH(false, true); }      /* fused inference is mlp_fwd16.hip's */
+#undef NERF_LAUNCH
+}
+template void launch_fwd_prec<NERF_TU == 1 ? NERF_PREC_BF16 : NERF_PREC_FP16>(const FwdArgs&, bool, bool, bool, dim3, dim3, hipStream_t);
+#endif
+}  // namespace mlp
+}  // namespace nerf
+
+#if NERF_TU == 0
 extern "C" int64_t nerf_mlp_saved_bytes(int64_t n_samples) {
     const int64_t n_tiles = (n_samples + TILE_SAMPLES - 1) / TILE_SAMPLES;
     return n_tiles * 8 * saved_bytes_per_wave_tile();
@@ -299,14 +394,8 @@ static int launch_fwd(const FwdArgs& a, int precision, bool encoded, void* strea
     const dim3 g((unsigned)grid), b(CHAIN_THREADS);
     hipStream_t st = (hipStream_t)stream;
     const bool save = a.saved != nullptr;
-#define NERF_LAUNCH(P, SV, EN) do { if (view) hipLaunchKernelGGL((mlp_fwd_kernel<P, SV, EN, true>), g, b, 0, st, a); \
-                                    else hipLaunchKernelGGL((mlp_fwd_kernel<P, SV, EN, false>), g, b, 0, st, a); } while (0)
-#define NERF_PICK(P)                                            \
-    if (save) { if (encoded) NERF_LAUNCH(P, true, true); else NERF_LAUNCH(P, true, false); } \
-    else { NERF_LAUNCH(P, false, true); }      /* fused inference is mlp_fwd16.hip's */
-    if (precision == NERF_PREC_BF16) { NERF_PICK(NERF_PREC_BF16) } else { NERF_PICK(NERF_PREC_FP16) }
-#undef NERF_PICK
-#undef NERF_LAUNCH
+    if (precision == NERF_PREC_BF16) launch_fwd_prec<NERF_PREC_BF16>(a, save, encoded, view, g, b, st);
+    else launch_fwd_prec<NERF_PREC_FP16>(a, save, encoded, view, g, b, st);
     return nerf_launch_status();
 }
 
@@ -421,3 +510,4 @@ extern "C" int nerf_mlp_fwd_encoded_static(int64_t M, const float* x_pts, const 
     if (rc) return rc;
     return fwd_encoded_impl(M, x_pts, x_views, packed, precision, raw, nullptr, ws, stream);
 }
+#endif   // NERF_TU == 0
