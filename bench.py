@@ -83,6 +83,8 @@ def parse():
                     help="the timed region of --steps steps is run this many times; the median region is reported")
     ap.add_argument("--big-batch", type=int, default=4096,
                     help="rays per GPU of the second training measurement (the data-parallel configuration's batch); 0 = skip")
+    ap.add_argument("--no-default-flags", action="store_true",
+                    help="skip the extra leg with the reference script's default flags (coarse only, no view directions)")
     ap.add_argument("--no-joint", action="store_true",
                     help="keep the per-network pack and weight-gradient launches in the single-process step (A/B switch)")
     ap.add_argument("--kernel-steps", type=int, default=10, help="eager steps with per-kernel HIP events after the timed region")
@@ -456,7 +458,7 @@ def main():
         big = train_leg(args, args.big_batch, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_ranks, 0,
                         step0=leg["next_step"])
     default_flags = None
-    if world == 1 and not args.no_render:
+    if world == 1 and not args.no_render and not args.no_default_flags:
         # the reference script's default flags (train_nerf.py:62, :79): coarse network only, no view directions
         from nerf_amd.models.nerf import NeRF, PositionalEncoder
         from nerf_amd.optim import FlatAdam

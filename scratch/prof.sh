@@ -5,7 +5,7 @@ set -e
 TAG=${1:-r2}
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
-B="python3 bench.py --steps 10 --warmup 3 --repeats 1 --big-batch 0 --no-cpu-baseline --no-one-eighth --kernel-steps 2"
+B="python3 bench.py --steps 10 --warmup 3 --repeats 1 --big-batch 0 --no-default-flags --no-cpu-baseline --no-one-eighth --kernel-steps 2"
 echo "$B" > $O/command.txt
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/trace_bench.json 2> $O/trace.err
 echo "trace done"
