@@ -4,8 +4,9 @@
 // are exact fp32 (the MFMA is a chain of fp32 fmas), so every ray meets the fp32 tolerance without a
 // conditioning mask; it runs at the fp32 matrix rate, 1/16 of the 16-bit kernels.
 //
-// Structure.  The network is a list of layers (a host-side "program").  A workgroup of four waves
-// owns 64 samples; their activations live in LDS for the whole network, as [k/4][sample][4] floats:
+// Structure.  The network is a list of layers (a host-side "program").  A workgroup of eight waves (two
+// per SIMD, so that one wave's operand latency is covered by the other's MFMAs; each wave owns one
+// 32-feature row tile of a layer at a time) owns 64 samples; their activations live in LDS for the whole network, as [k/4][sample][4] floats:
 // four consecutive input features of one sample are one 16-byte read, which is the B operand of four
 // MFMA k-steps (k-step j of an 8-feature chunk uses feature 4*(lane>>5) + j of the chunk on both
 // operands).  An output tile's accumulator (column = sample on the lane, rows = features in the
@@ -23,12 +24,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE = 64;                 // samples per workgroup
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;
+constexpr int WAVES = THREADS / 64;
 constexpr int MAX_W = NERF_FP32_MAX_WIDTH;
 constexpr int MAX_CP = NERF_FP32_MAX_PTS, MAX_CV = NERF_FP32_MAX_VIEWS;
 constexpr int BUF_FLOATS_H = MAX_W * TILE;          // 64 KiB
 constexpr int OFF_XP = 0, OFF_XV = OFF_XP + MAX_CP * TILE, OFF_HA = OFF_XV + MAX_CV * TILE, OFF_HB = OFF_HA + BUF_FLOATS_H;
-constexpr int LDS_FLOATS = OFF_HB + BUF_FLOATS_H;   // 152 KiB
+constexpr int OFF_RED = OFF_HB + BUF_FLOATS_H;      // partial sums of the output layers: [wave][sample][4 rows]
+constexpr int LDS_FLOATS = OFF_RED + WAVES * TILE * 4;   // 160 KiB
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 
 struct Program {
@@ -69,7 +72,45 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
         for (int li = 0; li < prog.n_layers; ++li) {
             const nerf_fp32_layer_t& L = prog.layer[li];
             const int n_ft = (L.out_features + 31) >> 5;
-            for (int ft = wave; ft < n_ft; ft += 4) {
+            if (L.dst == NERF_FP32_DST_RAW) {
+                // An output layer (at most 4 rows) is one row tile: instead of one wave working through all of K
+                // while seven wait, every wave takes an eighth of the input chunks and the partial sums of rows
+                // 0..3 (registers 0..3 of lane half 0) meet in LDS.
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+                for (int s = 0; s < L.n_segments; ++s) {
+                    const int nch = L.k_padded[s] >> 3;
+                    const f32x4* wf = reinterpret_cast<const f32x4*>(L.weights[s]) + lane;
+                    const f32x4* src = reinterpret_cast<const f32x4*>(lds + buf_off(L.src[s])) + h * TILE + n;
+                    for (int c = wave * nch / WAVES; c < (wave + 1) * nch / WAVES; ++c) {
+                        const f32x4 a = wf[(size_t)c * 64];
+                        const f32x4 b0 = src[(2 * c) * TILE], b1 = src[(2 * c) * TILE + 32];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc1, 0, 0, 0);
+                        }
+                    }
+                }
+                f32x4* red = reinterpret_cast<f32x4*>(lds + OFF_RED) + wave * TILE;
+                if (h == 0) {
+                    red[n] = f32x4{acc0[0], acc0[1], acc0[2], acc0[3]};
+                    red[32 + n] = f32x4{acc1[0], acc1[1], acc1[2], acc1[3]};
+                }
+                __syncthreads();
+                for (int idx = threadIdx.x; idx < TILE * 4; idx += THREADS) {
+                    const int smp = idx >> 2, row = idx & 3;
+                    if (row < L.out_features && m0 + smp < M) {
+                        float v = L.bias[row];
+                        for (int w = 0; w < WAVES; ++w) v += lds[OFF_RED + (w * TILE + smp) * 4 + row];
+                        raw[(m0 + smp) * 4 + L.dst_col + row] = L.relu ? fmaxf(v, 0.0f) : v;
+                    }
+                }
+                __syncthreads();              // the partial sums are read before another output layer rewrites them
+                continue;
+            }
+            for (int ft = wave; ft < n_ft; ft += WAVES) {
                 // accumulators of the two 32-sample halves start from the bias of rows 32 ft + row(r, h)
                 f32x16 acc0, acc1;
 #pragma unroll
@@ -82,32 +123,26 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
                     const int nch = L.k_padded[s] >> 3;
                     const f32x4* wf = reinterpret_cast<const f32x4*>(L.weights[s]) + ((size_t)ft * nch) * 64 + lane;
                     const f32x4* src = reinterpret_cast<const f32x4*>(lds + buf_off(L.src[s])) + h * TILE + n;
-                    f32x4 a = wf[0];
+                    // weights two chunks ahead (L2 latency), activations one chunk ahead (LDS latency)
+                    f32x4 a0 = wf[0], a1 = wf[(size_t)(1 < nch ? 1 : 0) * 64];
+                    f32x4 b0 = src[0], b1 = src[32];
                     for (int c = 0; c < nch; ++c) {
-                        const f32x4 a_next = wf[(size_t)(c + 1 < nch ? c + 1 : c) * 64];     // one chunk ahead
-                        const f32x4 b0 = src[(2 * c) * TILE], b1 = src[(2 * c) * TILE + 32];
+                        const int c1 = c + 1 < nch ? c + 1 : c, c2 = c + 2 < nch ? c + 2 : nch - 1;
+                        const f32x4 a2 = wf[(size_t)c2 * 64];
+                        const f32x4 nb0 = src[(2 * c1) * TILE], nb1 = src[(2 * c1) * TILE + 32];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc1, 0, 0, 0);
                         }
-                        a = a_next;
+                        a0 = a1; a1 = a2; b0 = nb0; b1 = nb1;
                     }
                 }
                 if (L.relu) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { acc0[r] = fmaxf(acc0[r], 0.0f); acc1[r] = fmaxf(acc1[r], 0.0f); }
                 }
-                if (L.dst == NERF_FP32_DST_RAW) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < L.out_features) {
-                            if (m0 + n < M) raw[(m0 + n) * 4 + L.dst_col + row] = acc0[r];
-                            if (m0 + 32 + n < M) raw[(m0 + 32 + n) * 4 + L.dst_col + row] = acc1[r];
-                        }
-                    }
-                } else {
+                {
                     f32x4* dst = reinterpret_cast<f32x4*>(lds + buf_off(L.dst));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

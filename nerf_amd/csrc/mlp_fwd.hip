@@ -124,7 +124,9 @@ __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t
 #endif
     __builtin_nontemporal_store(f, reinterpret_cast<frag*>(unit + (uint32_t)lane_off));
 }
-// one dword per lane at byte offset lane_off4 of the wave-uniform address `base`
+// one dword per lane at byte offset lane_off4 of the wave-uniform address `base`.  A plain store on purpose: the
+// sign masks of a step (75 MB at 1024 rays) then stay in the 256 MB last-level cache until the backward-data
+// pass reads them (stored non-temporally, that pass ran 10 % slower).
 __device__ __forceinline__ void save_dword(char* base, int lane_off4, uint32_t v) {
     *reinterpret_cast<uint32_t*>(base + (uint32_t)lane_off4) = v;
 }
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
         // store of raw may be skipped by a wave past the end and is not counted.
         constexpr int YOUNGER_THAN_INPUTS = VIEW ? 3 * DMA_PER_CHUNK + 10 : 4 * DMA_PER_CHUNK + 20;
         static_assert(fwd_block0(9) % CHUNK_BLOCKS == 0 && fwd_block0(7) % CHUNK_BLOCKS == 16, "chunk entries inside L9 / L7");
+        static_assert(ENCODED || SAVE, "the count above includes the unit and mask stores (fused inference is mlp_fwd16.hip's)");
 
         if (ENCODED) {
 #pragma unroll
