@@ -70,3 +70,29 @@ def test_cpu_tensors_are_rejected():
     assert [k for k, _ in m.named_parameters()][:2] == ["pts_linears.0.weight", "pts_linears.0.bias"]
     with pytest.raises(ValueError):
         m(torch.zeros(2, 63))          # same error as the reference when view encodings are missing
+
+
+def test_hand_issued_loads_are_not_touched_before_their_wait(tmp_path):
+    """The training forward loads the next pass's ray inputs by inline asm, which the compiler does not count:
+    its disassembly must not read, copy or spill a destination register between the load and the counted wait
+    (nerf_amd/csrc/audit_asm_loads.py; `make audit` does the same).  Needs the object files of the build."""
+    import shutil
+    import subprocess
+    import sys
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    objs = [os.path.join(ROOT, "build", "obj", "mlp_fwd.tu%d.o" % t) for t in (1, 2)]
+    if not all(os.path.exists(o) for o in objs) or not os.path.exists(objdump):
+        pytest.skip("object files of the build are not here")
+    for t, obj in enumerate(objs):
+        d = tmp_path / str(t)
+        d.mkdir()
+        shutil.copy(obj, d / "k.o")
+        subprocess.run([objdump, "--offloading", "k.o"], cwd=d, check=True, capture_output=True)
+        code = [f for f in os.listdir(d) if f.startswith("k.o.") and "gfx950" in f]
+        assert len(code) == 1, os.listdir(d)
+        with open(d / "k.s", "w") as f:
+            subprocess.run([objdump, "-d", code[0]], cwd=d, check=True, stdout=f)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "nerf_amd", "csrc", "audit_asm_loads.py"), str(d / "k.s")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 early uses" in r.stdout, r.stdout + r.stderr
+        assert int(r.stdout.split()[0]) >= 28, r.stdout        # the loads were found at all
