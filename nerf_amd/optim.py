@@ -79,7 +79,17 @@ class FlatAdam:
             b1, b2 = self.betas
             self._dev_state = torch.tensor([self.param_groups[0]["lr"], b1, b2, self.eps, 1.0, float(self.steps), 0.0,
                                             0.0], dtype=torch.float32, device=self.flat.device)
+            self._dev_lr = self.param_groups[0]["lr"]
         return self._dev_state
+
+    def set_lr(self, lr: float) -> None:
+        """The learning rate of the next step, on the host and in ``device_state()`` (the per-step decay of
+        train_nerf.py:288-290 survives graph replay this way); an unchanged rate costs no launch."""
+        self.param_groups[0]["lr"] = lr
+        state = self.device_state()
+        if lr != self._dev_lr:
+            state[0:1].fill_(lr)
+            self._dev_lr = lr
 
     @torch.no_grad()
     def step_dev(self, grads_gathered: bool = False) -> None:
@@ -141,4 +151,5 @@ class FlatAdam:
         if getattr(self, "_dev_state", None) is not None:
             b1, b2 = self.betas
             self._dev_state[:4].copy_(torch.tensor([self.param_groups[0]["lr"], b1, b2, self.eps]))
+            self._dev_lr = self.param_groups[0]["lr"]
             self._dev_state[5] = float(self.steps)

@@ -225,8 +225,7 @@ class TrainStep:
             if src is not dst:
                 dst.copy_(src, non_blocking=True)
         if lr is not None:
-            self.opt.param_groups[0]["lr"] = lr
-            self.opt.device_state()[0:1].fill_(lr)
+            self.opt.set_lr(lr)
         if self.use_graph:
             if self._g_fb is None:
                 self._capture()
