@@ -25,11 +25,11 @@ def short(n):
 
 
 def find(sub, name):
-    for root, _, files in os.walk(os.path.join(src, sub)):
-        for f in files:
-            if f.endswith(name):
-                return os.path.join(root, f)
-    raise FileNotFoundError(f"{sub}/**/{name}")
+    """newest match: results of earlier runs merged into the same directory stay behind under other process ids"""
+    hits = [os.path.join(root, f) for root, _, files in os.walk(os.path.join(src, sub)) for f in files if f.endswith(name)]
+    if not hits:
+        raise FileNotFoundError(f"{sub}/**/{name}")
+    return max(hits, key=os.path.getmtime)
 
 
 rows = list(csv.DictReader(open(find("trace", "kernel_stats.csv"))))
