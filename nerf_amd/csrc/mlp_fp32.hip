@@ -53,6 +53,71 @@ __device__ __forceinline__ void load_input(float* dst, const float* __restrict__
     }
 }
 
+// What a wave needs at the start of a layer and that does not depend on the layer before: the bias of its row
+// tile and the first two weight chunks.  They are requested one layer early, so that after the barrier the
+// first MFMA waits for LDS only (eight waves leaving a barrier together otherwise all wait a full L2 round
+// trip, twice: bias, then weights).  A wave owns at most one row tile per layer (width <= 256 = 8 tiles).
+struct Head {
+    f32x16 bias;
+    f32x4 a0, a1;
+};
+// A layer of more than four row tiles gives each wave one tile and both 32-sample halves of the workgroup's 64
+// samples; a narrower one (the 128-wide colour layer) gives waves w and w + 4 the same tile and one half each,
+// so that no wave idles.
+__device__ __forceinline__ bool halves_split(const nerf_fp32_layer_t& L) { return L.out_features <= 32 * (WAVES / 2); }
+__device__ __forceinline__ int row_tile_of(const nerf_fp32_layer_t& L, int wave) { return halves_split(L) ? (wave & (WAVES / 2 - 1)) : wave; }
+
+// The k loop of one row tile over a layer's input segments: HALVES = 2 accumulates both sample halves (two
+// independent MFMA chains), HALVES = 1 only the half starting at sample `first` (acc0).
+template <int HALVES>
+__device__ __forceinline__ void tile_chunks(const nerf_fp32_layer_t& L, const float* lds, const int* seg_off, int ft, int first,
+                                            int lane, const Head& head, f32x16& acc0, f32x16& acc1) {
+    const int n = lane & 31, h = lane >> 5;
+    for (int s = 0; s < L.n_segments; ++s) {
+        const int nch = L.k_padded[s] >> 3;
+        const f32x4* wf = reinterpret_cast<const f32x4*>(L.weights[s]) + ((size_t)ft * nch) * 64 + lane;
+        const f32x4* src = reinterpret_cast<const f32x4*>(lds + seg_off[s]) + h * TILE + first + n;
+        // weights two chunks ahead (L2 latency), activations one chunk ahead (LDS latency)
+        f32x4 a0 = head.a0, a1 = head.a1;
+        if (s > 0) { a0 = wf[0]; a1 = wf[(size_t)(1 < nch ? 1 : 0) * 64]; }
+        f32x4 b0 = src[0], b1 = HALVES == 2 ? src[32] : b0;
+        for (int c = 0; c < nch; ++c) {
+            const int c1 = c + 1 < nch ? c + 1 : c, c2 = c + 2 < nch ? c + 2 : nch - 1;
+            const f32x4 a2 = wf[(size_t)c2 * 64];
+            const f32x4 nb0 = src[(2 * c1) * TILE];
+            const f32x4 nb1 = HALVES == 2 ? src[(2 * c1) * TILE + 32] : nb0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc0, 0, 0, 0);
+                if (HALVES == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc1, 0, 0, 0);
+            }
+            a0 = a1; a1 = a2; b0 = nb0; b1 = nb1;
+        }
+    }
+}
+__device__ __forceinline__ Head load_head(const Program& prog, int li, int wave, int lane) {
+    Head hd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hd.bias[r] = 0.0f;
+    hd.a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    hd.a1 = hd.a0;
+    const nerf_fp32_layer_t& L = prog.layer[li];
+    const int h = lane >> 5;
+    const int ft = row_tile_of(L, wave);
+    if (L.dst != NERF_FP32_DST_RAW && 32 * ft < L.out_features) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < L.out_features) hd.bias[r] = L.bias[row];
+        }
+        const int nch = L.k_padded[0] >> 3;
+        const f32x4* wf = reinterpret_cast<const f32x4*>(L.weights[0]) + ((size_t)ft * nch) * 64 + lane;
+        hd.a0 = wf[0];
+        hd.a1 = wf[(size_t)(1 < nch ? 1 : 0) * 64];
+    }
+    return hd;
+}
+
 __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const float* __restrict__ x_pts, int cp,
                                                           const float* __restrict__ x_views, int cv, const Program prog,
                                                           float* __restrict__ raw) {
@@ -61,6 +126,8 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
     const int cp_pad = (cp + 7) & ~7, cv_pad = (cv + 7) & ~7;
+
+    Head next_head = load_head(prog, 0, wave, lane);
 
     for (int64_t tile = blockIdx.x; tile * TILE < M; tile += gridDim.x) {
         const int64_t m0 = tile * TILE;
@@ -72,6 +139,8 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
         for (int li = 0; li < prog.n_layers; ++li) {
             const nerf_fp32_layer_t& L = prog.layer[li];
             const int n_ft = (L.out_features + 31) >> 5;
+            const Head head = next_head;
+            next_head = load_head(prog, li + 1 < prog.n_layers ? li + 1 : 0, wave, lane);      // (after the last layer: the next tile's first)
             if (L.dst == NERF_FP32_DST_RAW) {
                 // An output layer (at most 4 rows) is one row tile: instead of one wave working through all of K
                 // while seven wait, every wave takes an eighth of the input chunks and the partial sums of rows
@@ -110,48 +179,27 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
                 __syncthreads();              // the partial sums are read before another output layer rewrites them
                 continue;
             }
-            for (int ft = wave; ft < n_ft; ft += WAVES) {
-                // accumulators of the two 32-sample halves start from the bias of rows 32 ft + row(r, h)
-                f32x16 acc0, acc1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float b = row < L.out_features ? L.bias[row] : 0.0f;
-                    acc0[r] = b; acc1[r] = b;
-                }
-                for (int s = 0; s < L.n_segments; ++s) {
-                    const int nch = L.k_padded[s] >> 3;
-                    const f32x4* wf = reinterpret_cast<const f32x4*>(L.weights[s]) + ((size_t)ft * nch) * 64 + lane;
-                    const f32x4* src = reinterpret_cast<const f32x4*>(lds + buf_off(L.src[s])) + h * TILE + n;
-                    // weights two chunks ahead (L2 latency), activations one chunk ahead (LDS latency)
-                    f32x4 a0 = wf[0], a1 = wf[(size_t)(1 < nch ? 1 : 0) * 64];
-                    f32x4 b0 = src[0], b1 = src[32];
-                    for (int c = 0; c < nch; ++c) {
-                        const int c1 = c + 1 < nch ? c + 1 : c, c2 = c + 2 < nch ? c + 2 : nch - 1;
-                        const f32x4 a2 = wf[(size_t)c2 * 64];
-                        const f32x4 nb0 = src[(2 * c1) * TILE], nb1 = src[(2 * c1) * TILE + 32];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc1, 0, 0, 0);
-                        }
-                        a0 = a1; a1 = a2; b0 = nb0; b1 = nb1;
-                    }
-                }
+            const bool split = halves_split(L);
+            const int ft = row_tile_of(L, wave);
+            if (ft < n_ft) {
+                // accumulators of the 32-sample halves start from the bias of rows 32 ft + row(r, h)
+                f32x16 acc0 = head.bias, acc1 = head.bias;
+                const int seg_off[2] = {buf_off(L.src[0]), buf_off(L.src[L.n_segments > 1 ? 1 : 0])};
+                const int first = split ? 32 * (wave / (WAVES / 2)) : 0;
+                if (split) tile_chunks<1>(L, lds, seg_off, ft, first, lane, head, acc0, acc1);
+                else tile_chunks<2>(L, lds, seg_off, ft, 0, lane, head, acc0, acc1);
                 if (L.relu) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { acc0[r] = fmaxf(acc0[r], 0.0f); acc1[r] = fmaxf(acc1[r], 0.0f); }
                 }
-                {
-                    f32x4* dst = reinterpret_cast<f32x4*>(lds + buf_off(L.dst));
+                f32x4* dst = reinterpret_cast<f32x4*>(lds + buf_off(L.dst));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int kq = 8 * ft + 2 * q + h;           // features 4 kq .. 4 kq + 3
-                        const f32x4 v0 = {acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
-                        const f32x4 v1 = {acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
-                        dst[kq * TILE + n] = v0;
-                        dst[kq * TILE + 32 + n] = v1;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int kq = 8 * ft + 2 * q + h;           // features 4 kq .. 4 kq + 3
+                    const f32x4 v0 = {acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
+                    const f32x4 v1 = {acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+                    dst[kq * TILE + first + n] = v0;
+                    if (!split) dst[kq * TILE + 32 + n] = v1;
                 }
             }
             __syncthreads();                  // the layer's output is complete before anyone reads it
