@@ -4,6 +4,8 @@
 //   mode 1: 32x32x16, one A block feeds two MFMAs (two sample tiles per wave: half the LDS bytes per FLOP)
 //   mode 2: 16x16x32, one A block feeds two MFMAs (two 16-sample column tiles)
 //   mode 3: 16x16x32, one A block feeds four MFMAs (four column tiles = 64 samples per wave)
+//   modes 4-7: as 0-3, but the reads run PF blocks ahead across the 32-block boundary as well (the kernels stop
+//              their read-ahead at every chunk entry and layer start: the data is only known to have landed there)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -20,11 +22,13 @@ template <int OFF> __device__ __forceinline__ i32x4 rd(uint32_t addr) {
 }
 template <int N> __device__ __forceinline__ void wt(i32x4& v) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N)); }
 
-template <int MODE>
+template <int MODE_>
 __global__ __launch_bounds__(512, 2) void k(const uint4* __restrict__ w, const uint4* __restrict__ x, float* out, int iters) {
     __shared__ uint4 lds[32 * 64];       // 32 blocks of 1 KiB
     for (int i = threadIdx.x; i < 32 * 64; i += 512) lds[i] = w[i];
     __syncthreads();
+    constexpr int MODE = MODE_ & 3;
+    constexpr bool WRAP = MODE_ >= 4;
     const int lane = threadIdx.x & 63;
     const uint32_t base = (uint32_t)(uintptr_t)lds + lane * 16;
     bf16x8 b[16];
@@ -32,11 +36,12 @@ __global__ __launch_bounds__(512, 2) void k(const uint4* __restrict__ w, const u
     f32x16 A0 = {0}, A1 = {0};
     f32x4 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     i32x4 a[32];
+    if (WRAP) { a[0] = rd<0>(base); a[1] = rd<1024>(base); a[2] = rd<2048>(base); a[3] = rd<3072>(base); }
     for (int it = 0; it < iters; ++it) {
-        a[0] = rd<0>(base); a[1] = rd<1024>(base); a[2] = rd<2048>(base); a[3] = rd<3072>(base);
+        if (!WRAP) { a[0] = rd<0>(base); a[1] = rd<1024>(base); a[2] = rd<2048>(base); a[3] = rd<3072>(base); }
 #define STEP(I)                                                                                         \
-        if ((I) + PF < 32) a[((I) + PF) & 31] = rd<(((I) + PF) & 31) * 1024>(base);                     \
-        if ((I) + PF < 32) wt<PF>(a[I]); else wt<31 - (I)>(a[I]);                                       \
+        if (WRAP || (I) + PF < 32) a[((I) + PF) & 31] = rd<(((I) + PF) & 31) * 1024>(base);             \
+        if (WRAP || (I) + PF < 32) wt<PF>(a[I]); else wt<31 - (I)>(a[I]);                               \
         {                                                                                               \
             const bf16x8 av = __builtin_bit_cast(bf16x8, a[I]);                                         \
             if (MODE == 0) {                                                                            \
@@ -82,15 +87,19 @@ int main() {
     hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
     const int iters = 4000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const double per_block[4] = {32768.0, 65536.0, 32768.0, 65536.0};   // flop per A block
+    const double per_block[8] = {32768.0, 65536.0, 32768.0, 65536.0, 32768.0, 65536.0, 32768.0, 65536.0};   // flop per A block
     for (int rep = 0; rep < 2; ++rep) {
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 8; ++mode) {
             hipEventRecord(e0);
             for (int r = 0; r < 5; ++r) {
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
                 else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
                 else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
-                else hipLaunchKernelGGL(k<3>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
+                else if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
+                else if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
+                else if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
+                else if (mode == 6) hipLaunchKernelGGL(k<6>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
+                else hipLaunchKernelGGL(k<7>, dim3(nblk), dim3(512), 0, 0, w, x, out, iters);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
