@@ -408,10 +408,11 @@ int nerf_mlp_fwd16_launch(int64_t n_rays, int S, const float* rays_o, const floa
 
 extern "C" int nerf_mlp_fwd(int64_t n_rays, int S, const float* rays_o, const float* rays_d, const float* z,
                             const void* packed, int precision, float* raw, void* saved, void* stream) {
-    NERF_REQUIRE(rays_o && rays_d && z && packed && raw, NERF_E_NULL);
     NERF_REQUIRE(n_rays >= 0 && S >= 1, NERF_E_SHAPE);
-    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256), NERF_E_ALIGN);
     NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
+    if (n_rays == 0) return NERF_OK;          // an empty call: its tensors have no address
+    NERF_REQUIRE(rays_o && rays_d && z && packed && raw, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256), NERF_E_ALIGN);
     if (saved == nullptr) return nerf_mlp_fwd16_launch(n_rays, S, rays_o, rays_d, z, packed, precision, raw, stream);
     FwdArgs a{};
     a.M = n_rays * S; a.n_tiles = (a.M + TILE_SAMPLES - 1) / TILE_SAMPLES; a.S = S;
@@ -452,10 +453,12 @@ static int fwd_encoded_impl(int64_t M, const float* x_pts, const float* x_views,
 
 extern "C" int nerf_mlp_fwd_encoded(int64_t M, const float* x_pts, const float* x_views, const void* packed,
                                     int precision, float* raw, void* saved, void* workspace, void* stream) {
+    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
+    NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
+    if (M == 0) return NERF_OK;               // an empty call: its tensors have no address
     NERF_REQUIRE(x_pts && packed && raw, NERF_E_NULL);
     NERF_REQUIRE(x_views || (precision & NERF_ARCH_NOVIEW), NERF_E_NULL);
     NERF_REQUIRE(saved || workspace, NERF_E_NULL);
-    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256) && nerf_aligned(saved, 256) &&
                  nerf_aligned(workspace, 256), NERF_E_ALIGN);
     NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
@@ -502,9 +505,11 @@ extern "C" int64_t nerf_mlp_fwd_encoded_static_max_samples(void) { return NERF_M
 
 extern "C" int nerf_mlp_fwd_encoded_static(int64_t M, const float* x_pts, const float* x_views, const void* packed,
                                            int precision, float* raw, void* stream) {
+    NERF_REQUIRE(M >= 0 && M <= NERF_MLP_FWD_ENCODED_STATIC_MAX, NERF_E_SHAPE);      // beyond the static buffer
+    NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
+    if (M == 0) return NERF_OK;               // an empty call: its tensors have no address
     NERF_REQUIRE(x_pts && packed && raw, NERF_E_NULL);
     NERF_REQUIRE(x_views || (precision & NERF_ARCH_NOVIEW), NERF_E_NULL);
-    NERF_REQUIRE(M >= 0 && M <= NERF_MLP_FWD_ENCODED_STATIC_MAX, NERF_E_SHAPE);      // beyond the static buffer
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(packed, 256), NERF_E_ALIGN);
     NERF_REQUIRE(nerf_prec_ok(precision), NERF_E_DTYPE);
     if (M == 0) return NERF_OK;

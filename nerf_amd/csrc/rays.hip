@@ -160,12 +160,12 @@ __global__ __launch_bounds__(256) void place_samples_kernel(int64_t total, int S
 
 extern "C" int nerf_get_rays(int H, int W, float focal, const float* c2w, int c2w_ld, int row0, int nrows,
                              float* rays_o, float* rays_d, void* stream) {
-    NERF_REQUIRE(c2w && rays_o && rays_d, NERF_E_NULL);
     NERF_REQUIRE(H > 0 && W > 0 && c2w_ld >= 4 && row0 >= 0 && nrows >= 0 && row0 + nrows <= H, NERF_E_SHAPE);
     NERF_REQUIRE(focal != 0.0f, NERF_E_SHAPE);
-    NERF_REQUIRE(nerf_aligned(rays_o, 16) && nerf_aligned(rays_d, 16), NERF_E_ALIGN);
     const int64_t npix = (int64_t)nrows * W;
-    if (npix == 0) return NERF_OK;
+    if (npix == 0) return NERF_OK;          // an empty call: its output tensors have no address
+    NERF_REQUIRE(c2w && rays_o && rays_d, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(rays_o, 16) && nerf_aligned(rays_d, 16), NERF_E_ALIGN);
     const int64_t groups = (npix + 3) / 4;
     int64_t blocks = (groups + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -178,12 +178,12 @@ extern "C" int nerf_gather_rays(int64_t n, const int64_t* pix, int n_images, int
                                 const float* poses, int pose_stride, const uint8_t* images, int channels,
                                 const float* lut, int white_bkgd, float* rays_o, float* rays_d, float* target,
                                 void* stream) {
-    NERF_REQUIRE(pix && poses && rays_o && rays_d, NERF_E_NULL);
-    NERF_REQUIRE((target == nullptr) || (images && lut), NERF_E_NULL);
     NERF_REQUIRE(n >= 0 && n_images >= 1 && H > 0 && W > 0 && pose_stride >= 12, NERF_E_SHAPE);
     NERF_REQUIRE(channels == 3 || channels == 4 || target == nullptr, NERF_E_SHAPE);
     NERF_REQUIRE(focal != 0.0f, NERF_E_SHAPE);
     if (n == 0) return NERF_OK;
+    NERF_REQUIRE(pix && poses && rays_o && rays_d, NERF_E_NULL);
+    NERF_REQUIRE((target == nullptr) || (images && lut), NERF_E_NULL);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(nerf::gather_rays_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, pix, H,
@@ -194,10 +194,10 @@ extern "C" int nerf_gather_rays(int64_t n, const int64_t* pix, int n_images, int
 extern "C" int nerf_place_samples(int64_t n_rays, int S, float near_s, float far_s, const float* near_ray,
                                   const float* far_ray, int lindisp, const float* z_override,
                                   const float* t_rand, float* z_out, void* stream) {
-    NERF_REQUIRE(z_out, NERF_E_NULL);
     NERF_REQUIRE(n_rays >= 0 && S >= 1 && S <= 65536, NERF_E_SHAPE);
     const int64_t total = n_rays * S;
     if (total == 0) return NERF_OK;
+    NERF_REQUIRE(z_out, NERF_E_NULL);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(nerf::place_samples_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(256) void posenc_kernel(int64_t total, int d, int L
 }  // namespace nerf
 
 extern "C" int nerf_posenc(int64_t n, int d, int L, const float* freqs, const float* x, float* out, void* stream) {
-    NERF_REQUIRE(x && out && (freqs || L == 0), NERF_E_NULL);
     NERF_REQUIRE(n >= 0 && d >= 1 && L >= 0 && L <= 64, NERF_E_SHAPE);
     const int64_t total = n * d * (1 + 2 * L);
     if (total == 0) return NERF_OK;
+    NERF_REQUIRE(x && out && (freqs || L == 0), NERF_E_NULL);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(nerf::posenc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total, d, L,

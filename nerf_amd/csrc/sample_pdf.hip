@@ -234,10 +234,10 @@ static inline int elems_per_lane(int n) {
 extern "C" int nerf_sample_pdf(int64_t n_rays, int n_bins, const float* bins, int64_t bins_ld,
                                const float* weights, int64_t w_ld, int n_samples, const float* u,
                                float* samples, int32_t* inds, void* stream) {
-    NERF_REQUIRE(bins && weights && samples, NERF_E_NULL);
     NERF_REQUIRE(n_rays >= 0 && n_bins >= 2 && n_bins <= 1024 && n_samples >= 1, NERF_E_SHAPE);
     NERF_REQUIRE(bins_ld >= n_bins && w_ld >= n_bins - 1, NERF_E_SHAPE);
-    if (n_rays == 0) return NERF_OK;
+    if (n_rays == 0) return NERF_OK;          // an empty call: its tensors have no address
+    NERF_REQUIRE(bins && weights && samples, NERF_E_NULL);
     const int lds_stride = (n_bins + 3) & ~3;
     const size_t lds = (size_t)4 * 2 * lds_stride * sizeof(float);
     const int64_t blocks = (n_rays + 3) / 4;
@@ -249,9 +249,9 @@ extern "C" int nerf_sample_pdf(int64_t n_rays, int n_bins, const float* bins, in
 
 extern "C" int nerf_sort_rows(int64_t n_rows, int n_a, const float* a, int n_b, const float* b, float* out,
                               void* stream) {
-    NERF_REQUIRE(a && out && (b || n_b == 0), NERF_E_NULL);
     NERF_REQUIRE(n_rows >= 0 && n_a >= 1 && n_b >= 0 && n_a + n_b <= 1024, NERF_E_SHAPE);
     if (n_rows == 0) return NERF_OK;
+    NERF_REQUIRE(a && out && (b || n_b == 0), NERF_E_NULL);
     const int64_t blocks = (n_rows + 3) / 4;
     NERF_REQUIRE(blocks <= 0x7fffffff, NERF_E_SHAPE);
     const dim3 grid((unsigned)blocks), block(256);
@@ -270,9 +270,9 @@ extern "C" int nerf_sort_rows(int64_t n_rows, int n_a, const float* a, int n_b, 
 
 extern "C" int nerf_sample_merge(int64_t n_rays, int Sc, const float* z_coarse, const float* w_coarse,
                                  int n_fine, const float* u, float* z_out, float* z_fine_out, void* stream) {
-    NERF_REQUIRE(z_coarse && w_coarse && z_out, NERF_E_NULL);
     NERF_REQUIRE(n_rays >= 0 && Sc >= 3 && Sc <= 1024 && n_fine >= 1 && Sc + n_fine <= 1024, NERF_E_SHAPE);
     if (n_rays == 0) return NERF_OK;
+    NERF_REQUIRE(z_coarse && w_coarse && z_out, NERF_E_NULL);
     const int lds_stride = (Sc + 3) & ~3, n_pad = (Sc + n_fine + 3) & ~3;
     const size_t lds = (size_t)4 * 2 * (lds_stride + n_pad) * sizeof(float);        // at most 64 KiB
     const int64_t blocks = (n_rays + 3) / 4;

@@ -162,6 +162,34 @@ def test_composite_empty(amd):
     assert outs[0].shape == (0, 3) and outs[4].shape == (0, 64)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_empty_inputs_everywhere(amd, precision):
+    """No rays, no rows: every public entry point returns empty results of the right shape, as the reference's
+    torch code does (an empty tensor has no address, so the C ABI must not ask for one), and a backward pass
+    over no rays leaves zero gradients.  One ray of two samples, the smallest ray batch the compositing takes."""
+    from nerf_amd import ops
+    from nerf_amd.models.nerf import NeRF, PositionalEncoder, render_rays, sample_pdf, render_hierarchical
+    pe, pv = PositionalEncoder(3, 10).to(DEV), PositionalEncoder(3, 4).to(DEV)
+    m = NeRF(precision=precision).to(DEV)
+    none = torch.zeros(0, 3, device=DEV)
+    out = render_rays(m, pe, pv, none, none, 2.0, 6.0, 64, False)
+    assert out["rgb_map"].shape == (0, 3) and out["weights"].shape == (0, 64) and out["depth_map"].shape == (0,)
+    assert m(torch.zeros(0, 63, device=DEV), torch.zeros(0, 27, device=DEV)).shape == (0, 4)
+    out = render_rays(m, pe, pv, none, none, 2.0, 6.0, 64, True)
+    out["rgb_map"].sum().backward()
+    assert all(p.grad is not None and not p.grad.any() for p in m.parameters())
+    if precision == "bf16":
+        coarse, fine = render_hierarchical(m, NeRF(precision=precision).to(DEV), pe, pv, none, none, 2.0, 6.0, 64, 128,
+                                           rand=False, det=True)
+        assert coarse["rgb_map"].shape == (0, 3) and fine["rgb_map"].shape == (0, 3) and fine["z_vals"].shape == (0, 192)
+    assert sample_pdf(torch.zeros(0, 63, device=DEV), torch.zeros(0, 62, device=DEV), 128, det=True).shape == (0, 128)
+    ro, rd = ops.get_rays(8, 8, 10.0, torch.eye(4, device=DEV)[:3].contiguous(), row0=3, nrows=0)
+    assert ro.shape == (0, 8, 3) and rd.shape == (0, 8, 3)
+    assert pe(none).shape == (0, 63)
+    one = render_rays(m, pe, pv, torch.zeros(1, 3, device=DEV), torch.ones(1, 3, device=DEV), 2.0, 6.0, 2, False)
+    assert one["rgb_map"].shape == (1, 3) and torch.isfinite(one["rgb_map"]).all()
+
+
 # ---------------------------------------------------------------------------
 def _margin_mask(cdf, u, tol=1e-6):
     """uniforms farther than tol from every CDF knot (index is then insensitive to 1-ulp CDF noise)"""
