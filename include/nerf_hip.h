@@ -17,6 +17,10 @@
  *     the call returns without synchronising;
  *   - return value: 0 = ok, negative = NERF_E_* argument error (nothing was
  *     launched), positive = a hipError_t from the launch.
+ *   - a call over nothing (zero rays, rows or samples) returns NERF_OK after
+ *     its sizes have been checked and before any pointer is looked at: the
+ *     tensors of an empty call have no address (the reference's torch code
+ *     returns empty tensors in that case).
  *   - entry points are re-entrant and keep no mutable global state.
  */
 #ifndef NERF_HIP_H

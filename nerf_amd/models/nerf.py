@@ -328,6 +328,7 @@ def render_rays(nerf_model, embed_fn_pts, embed_fn_views, rays_o: torch.Tensor, 
     if rays_o.dim() != 2 or rays_o.shape[-1] != 3 or rays_d.shape != rays_o.shape:
         raise RuntimeError(f"rays_o and rays_d must both be [N_rays, 3], got {tuple(rays_o.shape)} and "
                            f"{tuple(rays_d.shape)}")
+    rays_o, rays_d = ops._gpu_f32(rays_o, "rays_o"), ops._gpu_f32(rays_d, "rays_d")     # no CPU path: say so here
     n_rays = rays_o.shape[0]
     dev = rays_o.device
     if rand and t_rand is None:

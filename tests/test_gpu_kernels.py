@@ -35,6 +35,12 @@ def test_no_cpu_fallback(amd):
         ops.get_rays(4, 4, 5.0, torch.eye(4))
     with pytest.raises(RuntimeError):
         amd.sample_pdf(torch.rand(2, 5), torch.rand(2, 4), 8, det=True)
+    from nerf_amd.models.nerf import NeRF, PositionalEncoder, render_rays
+    m, pe, pv = NeRF().to(DEV), PositionalEncoder(3, 10).to(DEV), PositionalEncoder(3, 4).to(DEV)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        render_rays(m, pe, pv, torch.rand(4, 3), torch.rand(4, 3), 2.0, 6.0, 8, False)
+    with pytest.raises(TypeError, match="float32"):
+        render_rays(m, pe, pv, torch.rand(4, 3, device=DEV).double(), torch.rand(4, 3, device=DEV).double(), 2.0, 6.0, 8, False)
 
 
 # ---------------------------------------------------------------------------
