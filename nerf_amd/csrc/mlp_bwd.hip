@@ -560,7 +560,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
         __builtin_amdgcn_s_barrier();
         if (step + 3 < nsteps) {
             int st3 = stage + 3; if (st3 >= WG_STAGES) st3 -= WG_STAGES;
-            issue(step + 3, st3);       // its slot was read in the previous step (all waves passed the barrier since)
+            // Its slot was read in the previous step (all waves passed the barrier since).  The copies go out first:
+            // issued behind the first half's MFMAs instead, the pass ran 30 % slower -- a stage has three steps to
+            // arrive, and on the whole chip that is about the latency of a loaded HBM.
+            issue(step + 3, st3);
         }
         if (active) {
             const uint32_t sb = stage * WG_STAGE_BYTES;
@@ -580,7 +583,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) tb1[j] = NERF_TR(512, sb + b_unit[j]);
 #undef NERF_TR
-                tr_wait_all<TI, TJ, 0>(ta0, tb0);      // one LDS round trip per wave tile: both halves were requested above
+                // both halves were requested above; the first is complete once only the second half's reads (two per
+                // fragment, LDS returns in order) are outstanding, and those land behind the first half's MFMAs
+                constexpr int SECOND_HALF_READS = 2 * (TI + TJ) < 15 ? 2 * (TI + TJ) : 15;
+                tr_wait_all<TI, TJ, SECOND_HALF_READS>(ta0, tb0);
                 s16x8 af[TI], bf[TJ];
 #pragma unroll
                 for (int i = 0; i < TI; ++i) af[i] = tr_join(ta0[i]);
