@@ -553,6 +553,61 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
     if (nsteps > 1) issue(1, 1);
     if (nsteps > 2) issue(2, 2);
     int stage = 0;
+#ifndef NERF_WG_NO_STAGGER
+    // A SIMD holds waves w and w + 4 of the workgroup.  After a barrier both would read their fragments from LDS (MFMA
+    // pipe idle) and then both queue MFMAs (LDS idle).  In the 256 x 256 shapes waves 4..7 therefore run half a step
+    // late: they start a step with the MFMAs of the previous stage's second sample half (fragments kept in registers
+    // across the barrier) and read this stage's fragments behind them, so that on every SIMD one wave's LDS reads sit
+    // beside the other's MFMAs.  The ring protocol is the same (every wave has a stage's fragments in registers before
+    // the next barrier) and each wave adds the halves in the same order.  The late waves run a loop of their own: both
+    // orders inside one loop, or more than eight tiles per wave, make the kernel spill.
+    if (NSUB == 1 && TI * TJ <= 8 && wave >= 4) {
+        TrFrag ta0[TI], tb0[TJ], ta1[TI], tb1[TJ];             // the two 16-sample halves of the wave tile
+        auto contract_half = [&](TrFrag (&ta)[TI], TrFrag (&tb)[TJ]) {
+            s16x8 af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = tr_join(ta[i]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = tr_join(tb[j]);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) bsum[i] += frag_sum<PREC>(af[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
+        };
+        constexpr int SECOND_HALF_READS = 2 * (TI + TJ) < 15 ? 2 * (TI + TJ) : 15;
+        for (int step = 0; step < nsteps; ++step) {
+            const int younger = nsteps - 1 - step;
+            wait_stages(younger < 2 ? younger : 2);
+            __builtin_amdgcn_s_barrier();
+            if (step + 3 < nsteps) {
+                int st3 = stage + 3; if (st3 >= WG_STAGES) st3 -= WG_STAGES;
+                issue(step + 3, st3);
+            }
+            if (active) {
+                const uint32_t sb = stage * WG_STAGE_BYTES;
+                if (step > 0) contract_half(ta1, tb1);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) ta0[i] = tr_frag<0>(sb + a_unit[i]);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) tb0[j] = tr_frag<0>(sb + b_unit[j]);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) ta1[i] = tr_frag<512>(sb + a_unit[i]);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) tb1[j] = tr_frag<512>(sb + b_unit[j]);
+                tr_wait_all<TI, TJ, SECOND_HALF_READS>(ta0, tb0);
+                contract_half(ta0, tb0);
+                tr_wait_all<TI, TJ, 0>(ta1, tb1);              // in registers before the barrier that frees the slot
+            }
+            stage = stage + 1 == WG_STAGES ? 0 : stage + 1;
+        }
+        if (active && nsteps > 0) contract_half(ta1, tb1);
+    } else
+#endif
     for (int step = 0; step < nsteps; ++step) {
         // stage `step` landed (this wave's share); up to two younger stages may stay in flight
         const int younger = nsteps - 1 - step;
