@@ -43,11 +43,13 @@ struct ArchTab {
 // with per-workgroup clock stamps).  The kernel as a whole runs at the HBM rate, but a workgroup's own
 // rate depends on its GEMM's shape (the copies, LDS reads and MFMAs of a step are serial), so equal
 // bytes per workgroup do not end together; the work is divided by this cost instead.
+// The 256 x 256 shapes' 120 (131 by the stamps, before their waves 4..7 ran half a step late) is the best of
+// 105 / 112 / 120 / 125 / 131 by the time of the whole call.
 #ifndef NERF_WG_COST
-#define NERF_WG_COST {67, 131, 131, 131, 131, 146, 131, 131, 127, 24}
+#define NERF_WG_COST {67, 120, 120, 120, 120, 146, 120, 120, 127, 24}
 #endif
 #ifndef NERF_WG_COST_NV
-#define NERF_WG_COST_NV {67, 131, 131, 131, 131, 146, 131, 131, 50, 0}
+#define NERF_WG_COST_NV {67, 120, 120, 120, 120, 146, 120, 120, 50, 0}
 #endif
 constexpr ArchTab TAB_VIEW = {10, {
     {0, 16, 0, 0, SV_PE, 4, 0, 0},                  // 0: pts_linears.0
