@@ -17,8 +17,8 @@ median of --repeats timed regions of exactly --steps steps each.  The line also 
 with its all_gather and a frame-sharded slice of the 120-pose camera path.
 The timed steps replay the step from HIP graphs (a 1024-ray step is 25 short launches; issued from
 Python the host would be the bottleneck).  `roofline` describes the kernel with the largest share of
-GPU time in the step; its duration comes from HIP events recorded on the launch stream around every
-launch while the same step is issued eagerly right after the timed region.  `cpu_baseline` times the CPU oracle
+GPU time in the step, priced against the dense MFMA peak; its duration comes from HIP event-record nodes
+captured into a second copy of the step's graph around every C-ABI call and replayed right after the timed region.  `cpu_baseline` times the CPU oracle
 (oracle/nerf_oracle.py, a restatement of the reference's PyTorch path) on the same workload on
 this host's cores (rank 0, N = 1 only).
 """
@@ -282,7 +282,14 @@ def cpu_baseline(n_rays, steps):
         for _ in range(reps):
             O.render_hierarchical(pcd, pfd, ro, rd, 2.0, 6.0, 64, 128, det=True)
         dt_render = (time.perf_counter() - t1) / reps
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {"value": n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model, "torch_version": torch.__version__,
             "sample": f"{steps} training steps of {n_rays} rays (64+128 samples, fwd+bwd+Adam), fp32 torch CPU, "
                       f"{threads} threads, after 1 warm-up step",
             "render_rays_per_s": n_rays / dt_render,
@@ -353,18 +360,73 @@ def train_leg(args, n, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss")
     dt = sorted(regions)[len(regions) // 2]
-    times = None
+    times, timing = None, None
     if kernel_steps > 0:
-        # per-kernel durations: the same step issued eagerly with HIP events on the launch stream
+        times, timing = kernel_durations(mk, step_fn, kernel_steps, lr_at(it), sync)
+        it += kernel_steps + 1
+    return {"dt": dt, "regions_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
+            "graph_error": graph_error, "times": times, "timing": timing, "next_step": it}
+
+
+def kernel_durations(mk, step_fn, kernel_steps, lr, sync):
+    """Per-kernel GPU time of the training step: {name: (avg ms per call, calls, avg units per call, total ms)}.
+
+    The step is captured a second time with an event-record node in front of and behind every C-ABI call
+    (torch.cuda.Event(external=True) on the capture stream, i.e. the stream the kernels are launched on), and
+    that graph is replayed kernel_steps times: each replay stamps the events, so the durations are those inside
+    a graph-replayed step, launches back to back as in the timed region.  Where the runtime cannot time such
+    events the same step is issued eagerly with ordinary events instead, and the line says so."""
+    from nerf_amd import ops
+    acc = {}
+
+    def add(evs):
+        for name, lst in evs.items():
+            a = acc.setdefault(name, [0.0, 0, 0.0])
+            for e0, e1, u in lst:
+                a[0] += e0.elapsed_time(e1); a[1] += 1; a[2] += u
+
+    mode = "graph"
+    if step_fn.use_graph:
+        try:
+            ops.KERNEL_TIMES, ops.KERNEL_TIMES_IN_GRAPH = {}, True
+            st2 = mk(True)
+            st2.rays_o.copy_(step_fn.rays_o); st2.rays_d.copy_(step_fn.rays_d); st2.target.copy_(step_fn.target)
+            st2.prepare()
+            evs, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+            if not evs:
+                raise RuntimeError("no event was captured")
+            st2(st2.rays_o, st2.rays_d, st2.target, lr=lr)
+            for _ in range(kernel_steps):
+                st2(st2.rays_o, st2.rays_d, st2.target, lr=lr)
+                sync()
+                add(evs)
+            del st2
+        except Exception as e:      # noqa: BLE001
+            print("bench.py: in-graph kernel timing unavailable (%s: %s); timing eager launches"
+                  % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
+            mode, acc = "eager", {}
+        finally:
+            ops.KERNEL_TIMES, ops.KERNEL_TIMES_IN_GRAPH = None, False
+    else:
+        mode = "eager"
+    if mode == "eager":
+        was = step_fn.use_graph
         step_fn.use_graph = False
-        step_fn(rays_o, rays_d, target, lr=lr_at(it)); it += 1
+        step_fn(step_fn.rays_o, step_fn.rays_d, step_fn.target, lr=lr)
         ops.KERNEL_TIMES = {}
         for _ in range(kernel_steps):
-            step_fn(rays_o, rays_d, target, lr=lr_at(it)); it += 1
+            step_fn(step_fn.rays_o, step_fn.rays_d, step_fn.target, lr=lr)
         sync()
-        times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
-    return {"dt": dt, "regions_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
-            "graph_error": graph_error, "times": times, "next_step": it}
+        evs, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+        add(evs)
+        step_fn.use_graph = was
+    times = {k: (a[0] / a[1], a[1], a[2] / a[1], a[0]) for k, a in acc.items() if a[1]}
+    timing = ("HIP event-record nodes captured into the step's graph in front of and behind each C-ABI call, on the "
+              "stream the kernels are launched on; %d replays of that graph right after the timed region"
+              if mode == "graph" else
+              "HIP events on the launch stream around each C-ABI call, %d eager steps of the same training step run "
+              "right after the timed region") % kernel_steps
+    return times, timing
 
 
 def render_sharded_section(mc, mf, pe, pv, device, args, rank, world, sync, max_over_ranks):
@@ -498,42 +560,39 @@ def main():
         render_sharded = render_sharded_section(mc, mf, pe, pv, device, args, rank, world, sync, max_over_ranks)
 
     if rank == 0:
-        # per-kernel GPU time of the step (HIP events on the launch stream)
-        ktime = {}
-        for name, evs in times.items():
-            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-            ktime[name] = (tot_ms / len(evs), len(evs), sum(u for _, _, u in evs) / len(evs), tot_ms)
+        # per-kernel GPU time of the step (HIP events on the launch stream, inside the replayed graph)
+        ktime = times
         flop = {"mlp_fwd_train": MLP_FWD_FLOP, "mlp_fwd": MLP_FWD_FLOP, "mlp_bwd_data": MLP_DGRAD_FLOP,
                 "mlp_bwd_weights": MLP_WGRAD_FLOP}
         dom = max((k for k in ktime if k in flop), key=lambda k: ktime[k][3])
         avg_ms, launches, units, tot_ms = ktime[dom]
         mfma_kernel = units * flop[dom] / (avg_ms * 1e-3) / 1e12
+        # The MLP kernels are priced against the dense MFMA peak with the reference algorithm's unpadded FLOP
+        # counts: that is the bound a fused MLP has.  This design's weight-gradient pass also reads every saved
+        # activation and every dZ unit once (280 KiB per 32 samples), so its HBM rate is given beside it.
+        rl = {"bound": "mfma", "achieved": round(mfma_kernel, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(mfma_kernel / MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flop[dom]}
+        hbm = None
         if dom == "mlp_bwd_weights":
-            # the weight-gradient pass contracts over samples: every saved-activation unit and every dZ
-            # unit is read once, 280 KiB per 32 samples; it is HBM-bound in this design
             achieved = units * WGRAD_BYTES_PER_SAMPLE / (avg_ms * 1e-3) / 1e9
-            rl = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_sample": WGRAD_BYTES_PER_SAMPLE}
-        else:
-            rl = {"bound": "mfma", "achieved": round(mfma_kernel, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(mfma_kernel / MFMA_PEAK_TFLOPS, 4), "flop_per_sample": flop[dom]}
+            hbm = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(achieved / HBM_PEAK_GBS, 4), "bytes_per_sample": WGRAD_BYTES_PER_SAMPLE,
+                   "algorithmic_bytes_per_launch": round(units * WGRAD_BYTES_PER_SAMPLE)}
         rays_per_s = n * world * args.steps / dt
         traffic = measured_traffic(dom, n, args.precision)
         roofline = {"kernel": dom, **rl, "traffic": traffic,
                     "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE), rocprofv3 PMC passes of this "
                                     "command, profiles/traffic.json" if traffic is not None else "not collected",
-                    "algorithmic_bytes_per_launch": round(units * WGRAD_BYTES_PER_SAMPLE) if rl["bound"] == "hbm" else None,
-                    # the same kernel and the whole step against the dense MFMA peak, with the reference
-                    # algorithm's unpadded FLOP counts (2 x 593 408 per sample for the weight gradients;
-                    # 893.2 MFLOP per ray for forward + backward of the 64 + 192 evaluations)
+                    "hbm": hbm,
+                    # the whole step against the dense MFMA peak: 893.2 MFLOP per ray for forward + backward of
+                    # the 64 + 192 evaluations
                     "mfma_frac_kernel": round(mfma_kernel / MFMA_PEAK_TFLOPS, 4),
                     "step_mfma_frac": round(rays_per_s * MLP_FLOP_PER_RAY_TRAIN / (world * MFMA_PEAK_TFLOPS * 1e12), 4),
                     "mlp_flop_per_ray_fwd_bwd": MLP_FLOP_PER_RAY_TRAIN,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": launches,
                     "samples_per_launch": units,
-                    "timing": "HIP events on the launch stream around each C-ABI call (for mlp_bwd_weights: the "
-                              "contraction kernel plus its two small reduction kernels), %d eager steps of the same "
-                              "training step run right after the timed region" % args.kernel_steps}
+                    "timing": leg["timing"] + " (for mlp_bwd_weights: the contraction kernel plus its reduction "
+                                              "and factored-gradient kernels, one C-ABI call)"}
         kernels = {}
         for k, (a_ms, cnt, u, tot) in sorted(ktime.items()):
             entry = {"avg_us": round(a_ms * 1e3, 2), "launches": cnt,

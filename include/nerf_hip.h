@@ -21,7 +21,9 @@
  *     its sizes have been checked and before any pointer is looked at: the
  *     tensors of an empty call have no address (the reference's torch code
  *     returns empty tensors in that case).
- *   - entry points are re-entrant and keep no mutable global state.
+ *   - entry points are re-entrant and keep no mutable global state, with one
+ *     exception that says so in its own comment: nerf_mlp_fwd_encoded_static
+ *     (a per-device staging array inside the library, shared by all its calls).
  */
 #ifndef NERF_HIP_H
 #define NERF_HIP_H
@@ -95,8 +97,9 @@ int nerf_place_samples(int64_t n_rays, int S, float near_s, float far_s, const f
  * alpha compositing forward -- models/nerf.py:430-472.
  * raw [n_rays,S,4] (16-byte aligned), z [n_rays,S] ->
  * rgb_map [n_rays,3], depth/disp/acc [n_rays], weights [n_rays,S],
- * alpha [n_rays,S] (nullable).  2 <= S <= 1024 (with one sample the reference's own
- * interval list is empty and its outputs degenerate).
+ * alpha [n_rays,S] (nullable).  S >= 2, no upper limit as in the reference (with one
+ * sample the reference's own interval list is empty and its outputs degenerate);
+ * rays of more than 256 samples take a kernel with a run-time chunk loop.
  */
 int nerf_composite_fwd(int64_t n_rays, int S, const float *raw, const float *z, int white_bkgd,
                        float *rgb_map, float *depth_map, float *disp_map, float *acc_map, float *weights,
@@ -105,7 +108,9 @@ int nerf_composite_fwd(int64_t n_rays, int S, const float *raw, const float *z, 
 /* alpha compositing backward (the autograd of models/nerf.py:430-472).
  * Cotangents (each nullable = zero): g_rgb [n_rays,3], g_depth, g_disp, g_acc
  * [n_rays], g_weights, g_alpha [n_rays,S].  Output d_raw [n_rays,S,4].
- * The forward quantities are recomputed from raw and z.
+ * The forward quantities are recomputed from raw and z.  S >= 2; rays of more than
+ * 1024 samples take a two-pass kernel that keeps its per-chunk transmittance
+ * products in d_raw before overwriting them (d_raw must not alias raw).
  */
 int nerf_composite_bwd(int64_t n_rays, int S, const float *raw, const float *z, int white_bkgd,
                        const float *g_rgb, const float *g_depth, const float *g_disp, const float *g_acc,
@@ -243,7 +248,9 @@ int nerf_mlp_fp32_fwd(int64_t M, const float *x_pts, int cp, const float *x_view
  * 12 MiB that every GPU the library runs on holds until the process ends, so M is limited to
  * NERF_MLP_FWD_ENCODED_STATIC_MAX samples (NERF_E_SHAPE beyond that).  Results are bit-identical to
  * nerf_mlp_fwd_encoded.  All calls on one GPU share the one array: calls that overlap in time on the same
- * GPU (two streams, two threads) race; calls on one stream are ordered by the stream. */
+ * GPU (two streams, two threads) race; calls on one stream are ordered by the stream.  The first call on a
+ * device looks up that device's copy of the array (hipGetSymbolAddress, kept under a mutex: the library's only
+ * mutable state): make it outside stream capture; later calls on that device can be captured into a HIP graph. */
 #define NERF_MLP_FWD_ENCODED_STATIC_MAX 65536
 int64_t nerf_mlp_fwd_encoded_static_max_samples(void);
 int nerf_mlp_fwd_encoded_static(int64_t M, const float *x_pts, const float *x_views, const void *packed,
@@ -302,8 +309,8 @@ int nerf_adam_step(int64_t n, float *params, const float *grads, float *exp_avg,
 /* Same update with the hyper-parameters in device memory, so that the call can be captured in a
  * HIP graph and replayed while lr changes: state = device float[8] = {lr, beta1, beta2, eps,
  * grad_scale, step, ticket, scratch}.  The call applies the update of step state[5] + 1 and leaves
- * state[5] advanced by one (it starts from 0); state[6] must be 0 before the first call and is 0 again
- * after every call (a workgroup counter). */
+ * state[5] advanced by one (it starts from 0); state[6] is a workgroup counter the call clears itself
+ * (a 4-byte memset on the stream in front of the kernel) and leaves at 0: callers need not initialise it. */
 int nerf_adam_step_dev(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
                        float *state, void *stream);
 

@@ -9,8 +9,9 @@
         if (!(cond)) return (code); \
     } while (0)
 
-// Launch epilogue: report the launch error of the call just made (sticky errors
-// from earlier asynchronous work are not consumed here).
+// Launch epilogue: hipGetLastError() returns the last error recorded on this host thread and clears it.
+// Right after a launch that is the launch's own error (bad configuration, missing code object); an error
+// recorded by an earlier call that nobody collected is reported, and consumed, here as well.
 static inline int nerf_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? NERF_OK : (int)e;

@@ -30,7 +30,7 @@ __device__ __forceinline__ SampleFwd chunk_forward(const float4 r, float zk, flo
                                                    double& carry) {
     SampleFwd s;
     const float dist = last ? 1e10f : zn - zk;
-    const float sig = fmaxf(r.w, 0.0f);
+    const float sig = r.w < 0.0f ? 0.0f : r.w;          // relu that keeps a NaN a NaN, as torch.relu does (nerf.py:431)
     const float e = exp_hw(-sig * dist);
     s.alpha = valid ? 1.0f - e : 0.0f;
     s.de = valid ? dist * e : 0.0f;
@@ -239,6 +239,91 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n_rays, int 
     }
 }
 
+// Any S: the backward with a run-time chunk loop.  Pass 1 walks the ray front to back and leaves the running
+// transmittance product in front of every chunk in that chunk's first d_raw record (this wave's own output
+// rows, not yet written); pass 2 walks back to front, takes the product from there, recomputes the chunk and
+// overwrites the record with its result.  Same arithmetic and order of summation as the unrolled kernel.
+__global__ __launch_bounds__(256) void composite_bwd_long_kernel(int64_t n_rays, int S, const float4* __restrict__ raw,
+                                                                 const float* __restrict__ z, int white,
+                                                                 const float* __restrict__ g_rgb,
+                                                                 const float* __restrict__ g_depth,
+                                                                 const float* __restrict__ g_disp,
+                                                                 const float* __restrict__ g_acc,
+                                                                 const float* __restrict__ g_w,
+                                                                 const float* __restrict__ g_alpha,
+                                                                 float4* d_raw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int nch = (S + 63) >> 6;
+    for (int64_t ray = wave0; ray < n_rays; ray += nwaves) {
+        const int64_t base = ray * S;
+        double carry = 1.0;
+        float sd = 0.f, sa = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            const int k = c * 64 + lane;
+            const bool valid = k < S;
+            if (lane == 0) {
+                const long long bits = __builtin_bit_cast(long long, carry);
+                d_raw[base + k] = make_float4(__builtin_bit_cast(float, (int)bits), __builtin_bit_cast(float, (int)(bits >> 32)), 0.f, 0.f);
+            }
+            const float4 rc = valid ? raw[base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float zk = valid ? z[base + k] : 0.f;
+            const float zn = k + 1 < S ? z[base + k + 1] : 0.f;
+            const SampleFwd s = chunk_forward(rc, zk, zn, valid, k == S - 1, carry);
+            sd += s.w * zk; sa += s.w;
+        }
+        float gr = 0.f, gg = 0.f, gb = 0.f;
+        if (g_rgb) { gr = g_rgb[3 * ray]; gg = g_rgb[3 * ray + 1]; gb = g_rgb[3 * ray + 2]; }
+        float gD = g_depth ? g_depth[ray] : 0.f;
+        float gA = g_acc ? g_acc[ray] : 0.f;
+        if (white) gA -= (gr + gg) + gb;
+        if (g_disp) {
+            sd = wave_sum(sd); sa = wave_sum(sa);
+            const float den = sa + 1e-10f;
+            const float x = sd / den;
+            if (x > 1e-10f && !isnan(x)) {
+                const float gx = -g_disp[ray] / (x * x);
+                gD += gx / den;
+                gA += -gx * sd / (den * den);
+            }
+        }
+        // the products written above are read back by the lane that wrote them, once its stores have completed
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        float suffix_carry = 0.f;
+        for (int c = nch - 1; c >= 0; --c) {
+            const int k = c * 64 + lane;
+            const bool valid = k < S;
+            float4 head = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane == 0) head = d_raw[base + k];
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, head.x));
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, head.y));
+            double cprod = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+            const float4 rc = valid ? raw[base + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float zk = valid ? z[base + k] : 0.f;
+            const float zn = k + 1 < S ? z[base + k + 1] : 0.f;
+            const SampleFwd v = chunk_forward(rc, zk, zn, valid, k == S - 1, cprod);
+            float G = ((gr * v.cr + gg * v.cg) + gb * v.cb) + gD * zk + gA;
+            if (g_w && valid) G += g_w[base + k];
+            const float gw = valid ? G * v.w : 0.f;
+            const float incl = wave_incl_suffix_sum(gw, lane);
+            const float after = (incl - gw) + suffix_carry;
+            suffix_carry += read_lane(incl, 0);
+            float dalpha = G * v.T - after / v.q;
+            if (g_alpha && valid) dalpha += g_alpha[base + k];
+            const float dsig = rc.w > 0.0f ? dalpha * v.de : 0.0f;
+            if (valid) {
+                float4 o;
+                o.x = v.w * gr * (v.cr * (1.0f - v.cr));
+                o.y = v.w * gg * (v.cg * (1.0f - v.cg));
+                o.z = v.w * gb * (v.cb * (1.0f - v.cb));
+                o.w = dsig;
+                d_raw[base + k] = o;
+            }
+        }
+    }
+}
+
 // forward: 8 blocks of 4 waves per CU keep all 256 CUs full (the kernels stay under 64 VGPRs); each wave
 // then walks n_rays / 8192 rays
 static inline unsigned ray_grid_fwd(int64_t n_rays) {
@@ -258,7 +343,7 @@ static inline unsigned ray_grid(int64_t n_rays) {
 extern "C" int nerf_composite_fwd(int64_t n_rays, int S, const float* raw, const float* z, int white_bkgd,
                                   float* rgb_map, float* depth_map, float* disp_map, float* acc_map,
                                   float* weights, float* alpha, void* stream) {
-    NERF_REQUIRE(n_rays >= 0 && S >= 2 && S <= 1024, NERF_E_SHAPE);
+    NERF_REQUIRE(n_rays >= 0 && S >= 2, NERF_E_SHAPE);
     if (n_rays == 0) return NERF_OK;
     NERF_REQUIRE(raw && z && rgb_map && depth_map && disp_map && acc_map && weights, NERF_E_NULL);
     NERF_REQUIRE(nerf_aligned(raw, 16), NERF_E_ALIGN);
@@ -283,7 +368,7 @@ extern "C" int nerf_composite_bwd(int64_t n_rays, int S, const float* raw, const
                                   const float* g_rgb, const float* g_depth, const float* g_disp,
                                   const float* g_acc, const float* g_weights, const float* g_alpha,
                                   float* d_raw, void* stream) {
-    NERF_REQUIRE(n_rays >= 0 && S >= 2 && S <= 1024, NERF_E_SHAPE);
+    NERF_REQUIRE(n_rays >= 0 && S >= 2, NERF_E_SHAPE);
     if (n_rays == 0) return NERF_OK;
     NERF_REQUIRE(raw && z && d_raw, NERF_E_NULL);
     NERF_REQUIRE(nerf_aligned(raw, 16) && nerf_aligned(d_raw, 16), NERF_E_ALIGN);
@@ -301,7 +386,10 @@ extern "C" int nerf_composite_bwd(int64_t n_rays, int S, const float* raw, const
     else if (nch == 3) NERF_BWD(3);
     else if (nch == 4) NERF_BWD(4);
     else if (nch <= 8) NERF_BWD(8);
-    else NERF_BWD(16);
+    else if (nch <= 16) NERF_BWD(16);
+    else
+        hipLaunchKernelGGL(nerf::composite_bwd_long_kernel, grid, block, 0, st, n_rays, S, r4, z, white_bkgd, g_rgb,
+                           g_depth, g_disp, g_acc, g_weights, g_alpha, d4);
 #undef NERF_BWD
     return nerf_launch_status();
 }

@@ -39,6 +39,9 @@ struct Program {
     int n_layers;
 };
 
+// max(x, 0) that keeps a NaN a NaN, as torch.relu does (fmaxf would return 0: a diverged network must stay visible)
+__device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.0f ? 0.0f : x; }
+
 __device__ __forceinline__ int buf_off(int id) {
     return id == NERF_FP32_BUF_PTS ? OFF_XP : id == NERF_FP32_BUF_VIEWS ? OFF_XV : id == NERF_FP32_BUF_A ? OFF_HA : OFF_HB;
 }
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
                     if (row < L.out_features && m0 + smp < M) {
                         float v = L.bias[row];
                         for (int w = 0; w < WAVES; ++w) v += lds[OFF_RED + (w * TILE + smp) * 4 + row];
-                        raw[(m0 + smp) * 4 + L.dst_col + row] = L.relu ? fmaxf(v, 0.0f) : v;
+                        raw[(m0 + smp) * 4 + L.dst_col + row] = L.relu ? relu_keep_nan(v) : v;
                     }
                 }
                 __syncthreads();              // the partial sums are read before another output layer rewrites them
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
                 else tile_chunks<2>(L, lds, seg_off, ft, 0, lane, head, acc0, acc1);
                 if (L.relu) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { acc0[r] = fmaxf(acc0[r], 0.0f); acc1[r] = fmaxf(acc1[r], 0.0f); }
+                    for (int r = 0; r < 16; ++r) { acc0[r] = relu_keep_nan(acc0[r]); acc1[r] = relu_keep_nan(acc1[r]); }
                 }
                 f32x4* dst = reinterpret_cast<f32x4*>(lds + buf_off(L.dst));
 #pragma unroll
@@ -252,8 +255,13 @@ extern "C" int nerf_mlp_fp32_fwd(int64_t M, const float* x_pts, int cp, const fl
     NERF_REQUIRE(cp >= 1 && cp <= MAX_CP && cv >= 0 && cv <= MAX_CV && (x_views != nullptr || cv == 0), NERF_E_ARCH);
     Program prog;
     prog.n_layers = n_layers;
-    // every index a layer names is checked here: the kernel trusts the program
+    // Every index a layer names is checked here: the kernel trusts the program.  `width[b]` is how many
+    // features of buffer b hold defined values: the padded input widths, and for a hidden buffer the rows its
+    // last writer produced (whole 32-row tiles: rows past out_features come out as zeros).  A layer may not
+    // read beyond that, or it would multiply its zero-padded weights with stale LDS contents.
     int written = (1 << NERF_FP32_BUF_PTS) | (x_views ? 1 << NERF_FP32_BUF_VIEWS : 0);
+    int width[4] = {(cp + 7) & ~7, (cv + 7) & ~7, 0, 0};
+    int raw_cols = 0;
     for (int i = 0; i < n_layers; ++i) {
         const nerf_fp32_layer_t& L = layers[i];
         NERF_REQUIRE(L.n_segments >= 1 && L.n_segments <= 2 && L.bias, NERF_E_ARCH);
@@ -262,19 +270,21 @@ extern "C" int nerf_mlp_fp32_fwd(int64_t M, const float* x_pts, int cp, const fl
             NERF_REQUIRE(L.weights[s], NERF_E_NULL);
             NERF_REQUIRE(nerf_aligned(L.weights[s], 16), NERF_E_ALIGN);
             NERF_REQUIRE(L.src[s] >= NERF_FP32_BUF_PTS && L.src[s] <= NERF_FP32_BUF_B && ((written >> L.src[s]) & 1), NERF_E_ARCH);
-            const int cap = L.src[s] == NERF_FP32_BUF_PTS ? ((cp + 7) & ~7) : L.src[s] == NERF_FP32_BUF_VIEWS ? ((cv + 7) & ~7) : MAX_W;
-            NERF_REQUIRE(L.k_padded[s] >= 8 && L.k_padded[s] % 8 == 0 && L.k_padded[s] <= cap, NERF_E_ARCH);
+            NERF_REQUIRE(L.k_padded[s] >= 8 && L.k_padded[s] % 8 == 0 && L.k_padded[s] <= width[L.src[s]], NERF_E_ARCH);
             NERF_REQUIRE(L.src[s] != L.dst, NERF_E_ARCH);
         }
         if (L.dst == NERF_FP32_DST_RAW) {
             NERF_REQUIRE(L.dst_col >= 0 && L.dst_col + L.out_features <= 4, NERF_E_ARCH);
+            raw_cols |= ((1 << L.out_features) - 1) << L.dst_col;
         } else {
             NERF_REQUIRE(L.dst == NERF_FP32_BUF_A || L.dst == NERF_FP32_BUF_B, NERF_E_ARCH);
             NERF_REQUIRE(L.out_features <= MAX_W, NERF_E_ARCH);
             written |= 1 << L.dst;
+            width[L.dst] = (L.out_features + 31) / 32 * 32;
         }
         prog.layer[i] = L;
     }
+    NERF_REQUIRE(raw_cols == 0xf, NERF_E_ARCH);      // the program must write all four columns of raw
     const int64_t n_tiles = (M + TILE - 1) / TILE;
     const unsigned grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
     hipLaunchKernelGGL(mlp_fp32_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, M, x_pts, cp, x_views, cv, prog, raw);

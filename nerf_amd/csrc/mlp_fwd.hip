@@ -10,9 +10,27 @@
 #include <mutex>
 #include <type_traits>
 #include "mlp_chain.hpp"
+#include "mlp_waits.hpp"
 
 namespace nerf {
 namespace mlp {
+
+// chunk entries a wave passes while it consumes stream blocks [b0, b1): one per block that starts a chunk
+constexpr int chunk_entries(int b0, int b1) {
+    int n = 0;
+    for (int b = b0; b < b1; ++b) n += (b % CHUNK_BLOCKS == 0);
+    return n;
+}
+// vector-memory operations of a saving layer's tile epilogues: two unit stores per tile, one mask store per pair
+constexpr int epilogue_stores(int tiles) { return 2 * tiles + tiles / 2; }
+// What a wave issues between the next pass's input loads and their wait.  With view directions: L9 and L10
+// (the final store of raw may be skipped by a wave past the end and is not counted); without: L7 and the
+// output layer.
+static_assert(NERF_INPUTS_WAIT_VIEW == chunk_entries(fwd_block0(9), fwd_block0(11)) * DMA_PER_CHUNK +
+                                           epilogue_stores(FWD_TILES[9]), "mlp_waits.hpp: view network");
+static_assert(NERF_INPUTS_WAIT_NOVIEW == chunk_entries(fwd_block0(7), NV_FWD_BLOCKS_REAL) * DMA_PER_CHUNK +
+                                             epilogue_stores(FWD_TILES[7]), "mlp_waits.hpp: network without view directions");
+static_assert(NERF_INPUTS_WAIT_VIEW <= 63 && NERF_INPUTS_WAIT_NOVIEW <= 63, "vmcnt is a 6-bit counter");
 
 struct FwdArgs {
     int64_t M;            // samples
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
         // Operations between the next pass's loads and their use: without view directions L7 (4 chunk entries of 4
         // copies, 16 unit stores, 4 mask stores), else L9 (3 entries, 8 unit stores, 2 mask stores); the final
         // store of raw may be skipped by a wave past the end and is not counted.
-        constexpr int YOUNGER_THAN_INPUTS = VIEW ? 3 * DMA_PER_CHUNK + 10 : 4 * DMA_PER_CHUNK + 20;
+        constexpr int YOUNGER_THAN_INPUTS = VIEW ? NERF_INPUTS_WAIT_VIEW : NERF_INPUTS_WAIT_NOVIEW;
         static_assert(fwd_block0(9) % CHUNK_BLOCKS == 0 && fwd_block0(7) % CHUNK_BLOCKS == 16, "chunk entries inside L9 / L7");
         static_assert(ENCODED || SAVE, "the count above includes the unit and mask stores (fused inference is mlp_fwd16.hip's)");
 

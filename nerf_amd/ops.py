@@ -39,20 +39,30 @@ def _stream(dev: torch.device):
 # Optional per-kernel timing with events on the launch stream (used by bench.py for the roofline
 # figure).  KERNEL_TIMES maps a kernel name to a list of (start_event, end_event, units).
 KERNEL_TIMES = None
+# True: only calls made while the stream is being captured into a HIP graph are recorded, with events that
+# become record nodes of the graph ("external" events), so that every replay of the graph stamps them and
+# elapsed_time() between a pair is the duration inside the replayed step.
+KERNEL_TIMES_IN_GRAPH = False
 
 
 class _timed:
     def __init__(self, name, dev, units):
         self.name, self.dev, self.units = name, dev, units
+        self.on = False
 
     def __enter__(self):
-        if KERNEL_TIMES is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record(torch.cuda.current_stream(self.dev))
+        if KERNEL_TIMES is None:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        if KERNEL_TIMES_IN_GRAPH and not capturing:
+            return
+        self.on = True
+        self.e0 = torch.cuda.Event(enable_timing=True, external=capturing)
+        self.e1 = torch.cuda.Event(enable_timing=True, external=capturing)
+        self.e0.record(torch.cuda.current_stream(self.dev))
 
     def __exit__(self, *exc):
-        if KERNEL_TIMES is not None:
+        if self.on:
             self.e1.record(torch.cuda.current_stream(self.dev))
             KERNEL_TIMES.setdefault(self.name, []).append((self.e0, self.e1, self.units))
         return False
@@ -432,11 +442,8 @@ class _FusedMLP(torch.autograd.Function):
         dev = d_raw.device
         M = ctx.M
         dz = torch.empty((int(lib.nerf_mlp_dz_bytes(M)),), dtype=torch.uint8, device=dev)
-        part_bytes = int(lib.nerf_mlp_partial_bytes(M))
-        part = torch.empty((part_bytes,), dtype=torch.uint8, device=dev)
-        d_flat = torch.empty((ctx.n_params,), dtype=torch.float32, device=dev)
         scale = None
-        if ctx.fp16:
+        if ctx.fp16 and M > 0:
             # keep gradients inside the fp16 range: a power-of-two scale that puts max|d_raw| near 2^10
             amax = d_raw.abs().amax().clamp_min(1e-30)
             scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)).clamp(-24.0, 24.0)).reshape(1)
@@ -461,6 +468,9 @@ class _FusedMLP(torch.autograd.Function):
                                            n_params=ctx.n_params, shapes=ctx.shapes))
                 ctx.saved_acts = None
                 return (None,) * (8 + len(ctx.shapes))
+            part_bytes = int(lib.nerf_mlp_partial_bytes(M))
+            part = torch.empty((part_bytes,), dtype=torch.uint8, device=dev)
+            d_flat = torch.empty((ctx.n_params,), dtype=torch.float32, device=dev)
             with _timed("mlp_bwd_weights", dev, M):
                 check(lib.nerf_mlp_bwd_weights(M, _p(ctx.packed), _p(ctx.saved_acts), _p(dz), ctx.prec, _p(scale), _p(part),
                                                part_bytes, _p(d_flat), st), "nerf_mlp_bwd_weights")
@@ -598,7 +608,8 @@ def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, 
 
 def adam_step_dev(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                   state: torch.Tensor) -> None:
-    """Adam with hyper-parameters in the device tensor ``state`` = [lr, beta1, beta2, eps, grad_scale, step, -, -]."""
+    """Adam with hyper-parameters in the device tensor ``state`` = [lr, beta1, beta2, eps, grad_scale, step, ticket, -]
+    (the call clears the ticket itself)."""
     for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),
                   (state, "state")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):

@@ -9,7 +9,8 @@ import pytest
 from util import ROOT
 
 HEADER = os.path.join(ROOT, "include", "nerf_hip.h")
-LIB = os.path.join(ROOT, "nerf_amd", "lib", "libnerf_hip.so")
+# NERF_TEST_LIB: another build of the same library (the host-side sanitizer build of `make asan`)
+LIB = os.environ.get("NERF_TEST_LIB") or os.path.join(ROOT, "nerf_amd", "lib", "libnerf_hip.so")
 
 
 def declared_symbols():
@@ -46,8 +47,12 @@ def test_argument_errors_without_gpu():
     lib = ctypes.CDLL(LIB)
     lib.nerf_composite_fwd.restype = ctypes.c_int
     lib.nerf_composite_fwd.argtypes = [ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 7
-    assert lib.nerf_composite_fwd(4, 2000, None, None, 0, None, None, None, None, None, None, None) == -2   # S too large
+    assert lib.nerf_composite_fwd(4, 1, None, None, 0, None, None, None, None, None, None, None) == -2      # one sample
+    assert lib.nerf_composite_fwd(-1, 64, None, None, 0, None, None, None, None, None, None, None) == -2
     assert lib.nerf_composite_fwd(4, 64, None, None, 0, None, None, None, None, None, None, None) == -1     # NULL
+    assert lib.nerf_composite_fwd(4, 5000, None, None, 0, None, None, None, None, None, None, None) == -1   # no upper limit on S
+    assert lib.nerf_composite_fwd(4, 64, ctypes.c_void_p(8), *([ctypes.c_void_p(16)] * 1), 0,
+                                  *([ctypes.c_void_p(16)] * 6), None) == -3                                   # raw not 16-byte aligned
     lib.nerf_sort_rows.restype = ctypes.c_int
     lib.nerf_sort_rows.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     assert lib.nerf_sort_rows(1, 2000, ctypes.c_void_p(16), 0, None, ctypes.c_void_p(16), None) == -2
@@ -58,12 +63,45 @@ def test_argument_errors_without_gpu():
     assert lib.nerf_mlp_saved_bytes(1) == 8 * (142 + 9) * 1024 and lib.nerf_mlp_saved_bytes(257) == 16 * (142 + 9) * 1024
 
 
+def test_fp32_program_is_validated_on_the_host():
+    """nerf_mlp_fp32_fwd checks every index of the layer list before it launches: a layer that reads more features
+    of a hidden buffer than its producer wrote, a source that nothing wrote, or a program that leaves a column of
+    raw unwritten is refused with NERF_E_ARCH."""
+    from nerf_amd import _C
+    lib = ctypes.CDLL(LIB)
+    lib.nerf_mlp_fp32_fwd.restype = ctypes.c_int
+    lib.nerf_mlp_fp32_fwd.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    FAKE = 0x10000
+
+    def layer(k, src, out, dst, col=0):
+        L = _C.Fp32Layer()
+        L.n_segments = 1
+        L.weights[0], L.k_padded[0], L.src[0] = FAKE, k, src
+        L.bias, L.out_features, L.relu, L.dst, L.dst_col = FAKE, out, 1, dst, col
+        return L
+
+    def run(layers):
+        arr = (_C.Fp32Layer * len(layers))(*layers)
+        return lib.nerf_mlp_fp32_fwd(64, FAKE, 63, None, 0, ctypes.cast(arr, ctypes.c_void_p), len(layers), FAKE, None)
+
+    A, B, RAW, PTS = _C.FP32_BUF_A, _C.FP32_BUF_B, _C.FP32_DST_RAW, _C.FP32_BUF_PTS
+    assert run([layer(64, PTS, 100, A), layer(136, A, 4, RAW)]) == -4       # A holds 128 features (4 row tiles), not 136
+    assert run([layer(64, PTS, 100, A), layer(104, B, 4, RAW)]) == -4       # nothing wrote B
+    assert run([layer(64, PTS, 100, A), layer(104, A, 3, RAW)]) == -4       # column 3 of raw stays unwritten
+    assert run([layer(72, PTS, 100, A), layer(104, A, 4, RAW)]) == -4       # 63 encoded features pad to 64, not 72
+    assert run([layer(64, PTS, 100, A), layer(104, A, 3, RAW, 2)]) == -4    # columns 2..4
+
+
 def test_cpu_tensors_are_rejected():
-    """the product has no CPU path: CPU tensors raise before reaching the library"""
+    """the kernels have no CPU path: CPU tensors raise before reaching the library (get_rays alone serves a pose
+    in host memory, with torch CPU ops, as the reference's loader workers need)"""
     import torch
     import nerf_amd
+    from nerf_amd import ops
     with pytest.raises(RuntimeError):
-        nerf_amd.get_rays(4, 4, 5.0, torch.eye(4))
+        ops.get_rays(4, 4, 5.0, torch.eye(4))
+    assert nerf_amd.get_rays(4, 4, 5.0, torch.eye(4))[0].device.type == "cpu"
     with pytest.raises(RuntimeError):
         nerf_amd.PositionalEncoder(3, 10)(torch.zeros(2, 3))
     m = nerf_amd.NeRF()

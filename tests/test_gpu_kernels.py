@@ -139,9 +139,11 @@ def test_composite_golden(amd, golden):
         assert maxabs(gr2, ref2) < 1e-4 * ref2.abs().max().item()
 
 
-@pytest.mark.parametrize("S", [2, 7, 64, 65, 128, 192, 256, 300, 700])
+@pytest.mark.parametrize("S", [2, 7, 64, 65, 128, 192, 256, 300, 700, 1024, 1025, 1500, 2113])
 def test_composite_sizes(amd, S):
-    """Ragged and multi-chunk sample counts, all outputs and all cotangents incl. disp and alpha."""
+    """Ragged and multi-chunk sample counts, all outputs and all cotangents incl. disp and alpha.  The reference
+    has no upper limit on the samples per ray (nerf.py:377-409): beyond 256 the forward, and beyond 1024 the
+    backward, run their run-time chunk loops."""
     from nerf_amd import ops
     gen = torch.Generator().manual_seed(S)
     N = 37
@@ -168,7 +170,7 @@ def test_composite_empty(amd):
     assert outs[0].shape == (0, 3) and outs[4].shape == (0, 64)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32"])
 def test_empty_inputs_everywhere(amd, precision):
     """No rays, no rows: every public entry point returns empty results of the right shape, as the reference's
     torch code does (an empty tensor has no address, so the C ABI must not ask for one), and a backward pass

@@ -193,3 +193,100 @@ def test_adam_matches_torch(amd):
         opt.step()
         ops.adam_step(p, gr.to(DEV), m, v, 5e-4, 0.9, 0.999, 1e-8, step)
         assert maxabs(p, ref) < 2e-6      # fp32 update of O(5e-4) steps on O(1) parameters
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_train_step_golden_lindisp_white(amd, golden, precision):
+    """The training step with the flags of the camera-path configuration (train_nerf.py:293-331 with
+    lindisp=True, white_bkgd=True) against what the reference itself computed on the same uniforms
+    (oracle/gen_golden_f9b.py): graph-replayed TrainStep in the 16-bit modes, the explicit call sequence in the
+    fp32 mode.  Losses 1e-5 / 1e-4 (fp32) or 2e-3 (16 bit); gradients 2e-3 (fp32), 25 % bf16 / 10 % fp16 against
+    the fp32 reference (ReLU mask flips, see the head of this file)."""
+    from nerf_amd.optim import FlatAdam
+    from nerf_amd.train import TrainStep
+    g = golden("f9b_train_step_lindisp_white")
+    ro, rd, tgt = T(g["rays_o"], DEV), T(g["rays_d"], DEV), T(g["target"], DEV)
+    n = ro.shape[0]
+    t1, uu, t2 = T(g["t_rand_coarse"], DEV), T(g["u_fine"], DEV), T(g["t_rand_fine"], DEV)
+    mc, mf = amd_model(O.init_params(0), precision), amd_model(O.init_params(1), precision)
+    pe, pv = amd.PositionalEncoder(3, 10).to(DEV), amd.PositionalEncoder(3, 4).to(DEV)
+    if precision == "fp32":
+        c, f = amd.render_hierarchical(mc, mf, pe, pv, ro, rd, 2.0, 6.0, 64, 128, rand=True, det=False, lindisp=True,
+                                       white_bkgd=True, t_rand_coarse=t1, u_fine=uu, t_rand_fine=t2)
+        assert maxabs(c["z_vals"].reshape(-1), torch.sort(c["z_vals"], -1).values.reshape(-1)) == 0.0
+        loss_c, loss_f = torch.mean((c["rgb_map"] - tgt) ** 2), torch.mean((f["rgb_map"] - tgt) ** 2)
+        (loss_c + loss_f).backward()
+        assert maxabs(c["rgb_map"], T(g["c_rgb_map"])) < 1e-3
+        grads = {"c": {k: p.grad for k, p in mc.named_parameters()}, "f": {k: p.grad for k, p in mf.named_parameters()}}
+        lc, lf, ltol_c, ltol_f, lim = loss_c.item(), loss_f.item(), 1e-5, 1e-4, 2e-3
+    else:
+        opt = FlatAdam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
+        step = TrainStep(mc, mf, pe, pv, opt, n, lindisp=True, white_bkgd=True, use_graph=True, external_uniforms=True)
+        step.uniforms.copy_(torch.cat([t1.reshape(-1), uu.reshape(-1), t2.reshape(-1)]))
+        w0 = opt.flat.clone()
+        step(ro, rd, tgt, lr=0.0)                   # lr = 0: gradients, no update
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat, w0)
+        lc, lf = step.loss_coarse.item(), step.loss_fine.item()
+        assert abs(step.loss.item() - (lc + lf)) < 1e-6
+        grads, off = {"c": {}, "f": {}}, 0
+        for tag, m in (("c", mc), ("f", mf)):
+            for k, p in m.named_parameters():
+                grads[tag][k] = opt.flat_grad[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+        ltol_c = ltol_f = 2e-3
+        lim = 0.25 if precision == "bf16" else 0.1
+    assert abs(lc - float(g["loss_c"])) < ltol_c * float(g["loss_c"]), (lc, float(g["loss_c"]))
+    assert abs(lf - float(g["loss_f"])) < ltol_f * float(g["loss_f"]), (lf, float(g["loss_f"]))
+    for tag in ("c", "f"):
+        norms = np.array([v.double().norm().item() for v in grads[tag].values()])
+        assert np.all(np.abs(norms - g[f"gnorm_{tag}"]) < lim * g[f"gnorm_{tag}"] + 1e-12), (tag, norms / g[f"gnorm_{tag}"])
+        assert _rel(grads[tag]["sigma_linear.weight"].cpu(), T(g[f"g_{tag}_sigma_w"])) < lim
+        assert _rel(grads[tag]["rgb_layers.2.weight"].cpu(), T(g[f"g_{tag}_rgb2_w"])) < lim
+        assert _rel(grads[tag]["pts_linears.0.bias"].cpu(), T(g[f"g_{tag}_l0_b"])) < 2 * lim
+        assert _rel(grads[tag]["pts_linears.5.weight"].cpu()[:8, :80], T(g[f"g_{tag}_l5_w_head"])) < 2 * lim
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("where", ["pts_linears.3.weight", "sigma_linear.bias", "rgb_layers.2.weight"])
+def test_nan_weight_gives_non_finite_loss(amd, precision, where):
+    """A diverged network stays visible: with a NaN in a weight the reference's loss is NaN (torch.relu keeps a
+    NaN, nerf.py:178, :431), and so is this one's -- through the fused kernels' integer-maximum ReLU, the fp32
+    kernel's and the compositing kernel's."""
+    gen = torch.Generator().manual_seed(5)
+    n = 64
+    ro, rd = O.synthetic_rays(n, seed=2)
+    params = {k: v.clone() for k, v in O.init_params(0).items()}
+    params[where].view(-1)[0] = float("nan")
+    m = amd_model(params, precision)
+    pe, pv = amd.PositionalEncoder(3, 10).to(DEV), amd.PositionalEncoder(3, 4).to(DEV)
+    out = amd.render_rays(m, pe, pv, ro.to(DEV), rd.to(DEV), 2.0, 6.0, 64, rand=True,
+                          t_rand=torch.rand(n, 64, generator=gen).to(DEV))
+    loss = torch.mean((out["rgb_map"] - torch.rand(n, 3, generator=gen).to(DEV)) ** 2)
+    assert not torch.isfinite(loss).item(), (precision, where, loss.item())
+    loss.backward()
+    assert not all(torch.isfinite(p.grad).all().item() for p in m.parameters())
+
+
+def test_adam_dev_clears_its_ticket(amd):
+    """nerf_adam_step_dev with garbage in the workgroup counter of its state (a caller that did not initialise it,
+    or a launch that aborted): the call clears the counter itself, the step count advances by one per call and
+    the update equals torch.optim.Adam's."""
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(1)
+    n = 70001
+    p0 = torch.randn(n, generator=gen)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=5e-4)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.tensor([5e-4, 0.9, 0.999, 1e-8, 1.0, 0.0, 0.0, 0.0], device=DEV)
+    for step in range(1, 5):
+        state.view(torch.int32)[6] = 12345 * step          # garbage ticket
+        gr = torch.randn(n, generator=gen) * 0.1
+        ref.grad = gr.clone()
+        opt.step()
+        ops.adam_step_dev(p, gr.to(DEV), m, v, state)
+        torch.cuda.synchronize()
+        assert state[5].item() == float(step) and state.view(torch.int32)[6].item() == 0
+        assert maxabs(p, ref) < 2e-6

@@ -244,3 +244,34 @@ def test_wellconditioned_fixture_matches_oracle(golden):
     for k in ("rgb_map", "depth_map", "acc_map"):
         assert (c[k] - T(g[f"c_{k}_l1w1"])).abs().max() < 1e-4
         assert (f[k] - T(g[f"f_{k}_l1w1"])).abs().max() < 1e-3
+
+
+def test_get_rays_host_branch_matches_reference_golden(golden):
+    """A pose in host memory (the reference's DataLoader workers, datasets/blender.py:151) takes the package's
+    torch-op branch: bit-identical to the rays the reference itself produced (golden f1; 1e-7 allowed on the
+    directions for CPUs whose vectorised kernels round differently), same shapes, device and contiguity, the
+    reference's own known answers (tests/test_ray_utils.py:56-143), and a row block equals the slice."""
+    from util import O, T
+    from nerf_amd.utils.ray_utils import get_rays
+    g = golden("f1_get_rays")
+    for nm in ("identity", "sph40"):
+        c2w = T(g[nm + "_c2w"])
+        ro, rd = get_rays(8, 8, 5.0, c2w)
+        assert ro.device.type == "cpu" and ro.dtype == torch.float32 and ro.is_contiguous() and rd.is_contiguous()
+        assert ro.shape == rd.shape == (8, 8, 3)
+        assert torch.equal(ro, T(g[nm + "_o8"]))
+        assert (rd - T(g[nm + "_d8"])).abs().max() <= 1e-7
+        oro, ord_ = O.get_rays(8, 8, 5.0, c2w)
+        assert torch.equal(rd, ord_) and torch.equal(ro, oro)        # same op order as the restatement, same machine
+        ro, rd = get_rays(800, 800, float(g["focal800"]), c2w[:3])   # [3,4] pose
+        assert (rd[392:408, 792:800] - T(g[nm + "_d800_crop"])).abs().max() <= 1e-7
+        assert (rd[:4, :4] - T(g[nm + "_d800_corner"])).abs().max() <= 1e-7
+        rb_o, rb_d = get_rays(800, 800, float(g["focal800"]), c2w, row0=300, nrows=17)
+        assert torch.equal(rb_d, rd[300:317]) and torch.equal(rb_o, ro[300:317])
+    ro, rd = get_rays(4, 4, 5.0, torch.eye(4))
+    assert torch.equal(ro, torch.zeros(4, 4, 3)) and torch.allclose(rd[2, 2], torch.tensor([0.0, 0.0, -1.0]), atol=1e-6)
+    tl = torch.tensor([-0.4, -0.4, -1.0])
+    assert torch.allclose(rd[0, 0], tl / tl.norm(), atol=1e-6)
+    assert torch.allclose(rd.norm(dim=-1), torch.ones(4, 4), atol=1e-6)
+    with pytest.raises(ValueError):
+        get_rays(4, 4, 5.0, torch.eye(3))

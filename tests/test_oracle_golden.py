@@ -150,3 +150,19 @@ def test_train_step(golden):
         norms = np.array([v.grad.double().norm().item() for v in p.values()])
         np.testing.assert_allclose(norms, g[f"gnorm_{tag}"], rtol=2e-3, atol=1e-9)
         close(p["sigma_linear.weight"].grad, g[f"g_{tag}_sigma_w"], atol=1e-3 * np.abs(g[f"g_{tag}_sigma_w"]).max())
+
+
+def test_train_step_lindisp_white(golden):
+    """the oracle against the reference's training step with lindisp + white background (gen_golden_f9b.py)"""
+    g = golden("f9b_train_step_lindisp_white")
+    pc = {k: v.requires_grad_(True) for k, v in O.init_params(0).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.init_params(1).items()}
+    tot, lc, lf, c, f = O.train_step_loss(pc, pf, T(g["rays_o"]), T(g["rays_d"]), T(g["target"]), 2.0, 6.0, 64, 128,
+                                          T(g["t_rand_coarse"]), T(g["u_fine"]), T(g["t_rand_fine"]), lindisp=True,
+                                          white_bkgd=True)
+    tot.backward()
+    close(lc.detach(), g["loss_c"], rtol=1e-5); close(lf.detach(), g["loss_f"], rtol=1e-5)
+    close(c["rgb_map"].detach(), g["c_rgb_map"], atol=1e-5)
+    for tag, p in (("c", pc), ("f", pf)):
+        norms = np.array([v.grad.double().norm().item() for v in p.values()])
+        np.testing.assert_allclose(norms, g[f"gnorm_{tag}"], rtol=2e-3, atol=1e-9)
