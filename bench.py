@@ -17,7 +17,7 @@ median of --repeats timed regions of exactly --steps steps each.  The line also 
 with its all_gather and a frame-sharded slice of the 120-pose camera path.
 The timed steps replay the step from HIP graphs (a 1024-ray step is 25 short launches; issued from
 Python the host would be the bottleneck).  `roofline` describes the kernel with the largest share of
-GPU time in the step, priced against the dense MFMA peak; its duration comes from HIP event-record nodes
+GPU time in the step, priced against the dense MFMA peak; its duration comes from one-lane time-stamp kernels
 captured into a second copy of the step's graph around every C-ABI call and replayed right after the timed region.  `cpu_baseline` times the CPU oracle
 (oracle/nerf_oracle.py, a restatement of the reference's PyTorch path) on the same workload on
 this host's cores (rank 0, N = 1 only).
@@ -362,70 +362,109 @@ def train_leg(args, n, mc, mf, pe, pv, opt, device, rank, world, sync, max_over_
     dt = sorted(regions)[len(regions) // 2]
     times, timing = None, None
     if kernel_steps > 0:
-        times, timing = kernel_durations(mk, step_fn, kernel_steps, lr_at(it), sync)
+        times, timing = kernel_durations(mk, step_fn, kernel_steps, lr_at(it), sync, device)
         it += kernel_steps + 1
     return {"dt": dt, "regions_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
             "graph_error": graph_error, "times": times, "timing": timing, "next_step": it}
 
 
-def kernel_durations(mk, step_fn, kernel_steps, lr, sync):
+class Stamper:
+    """Slots of the device's 100 MHz counter written by one-lane kernels of libnerf_bench.so
+    (nerf_amd/csrc/bench_stamp.hip); ``__call__(stream)`` enqueues a stamp and returns its slot."""
+
+    def __init__(self, device, names=None, n_slots=4096):
+        self.names = names          # only calls with these names are stamped (None: all)
+        self.pair = None            # two stamps taken back to back: what a stamp itself adds to an interval
+        import ctypes
+        path = os.path.join(ROOT, "nerf_amd", "lib", "libnerf_bench.so")
+        self.lib = ctypes.CDLL(path)
+        self.lib.nerf_bench_stamp.restype = ctypes.c_int
+        self.lib.nerf_bench_stamp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.nerf_bench_stamp_rate.restype = ctypes.c_int64
+        self.rate = float(self.lib.nerf_bench_stamp_rate())
+        self.slots = torch.zeros((n_slots,), dtype=torch.int64, device=device)
+        self.used = 0
+
+    def __call__(self, stream):
+        if self.pair is None:
+            self.pair = ()
+            self.pair = (self(stream), self(stream))
+            return self.pair[1]
+        if self.used >= self.slots.numel():
+            raise RuntimeError("out of time-stamp slots")
+        i = self.used
+        self.used += 1
+        rc = self.lib.nerf_bench_stamp(self.slots.data_ptr() + 8 * i, stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError("nerf_bench_stamp failed with %d" % rc)
+        return i
+
+
+def kernel_durations(mk, step_fn, kernel_steps, lr, sync, device):
     """Per-kernel GPU time of the training step: {name: (avg ms per call, calls, avg units per call, total ms)}.
 
-    The step is captured a second time with an event-record node in front of and behind every C-ABI call
-    (torch.cuda.Event(external=True) on the capture stream, i.e. the stream the kernels are launched on), and
-    that graph is replayed kernel_steps times: each replay stamps the events, so the durations are those inside
-    a graph-replayed step, launches back to back as in the timed region.  Where the runtime cannot time such
-    events the same step is issued eagerly with ordinary events instead, and the line says so."""
+    The step is captured a second time with a one-lane time-stamp kernel in front of and behind every C-ABI call
+    (on the capture stream, i.e. the stream the kernels are launched on), and that graph is replayed kernel_steps
+    times: each replay stamps the slots, so the durations are those inside a graph-replayed step, launches back to
+    back as in the timed region (HIP event records cannot be captured into a graph on ROCm).  The first stamp of a
+    replay is taken twice, back to back: that distance -- one stamp kernel and one launch boundary, what the
+    stamping itself adds -- is subtracted from every interval.  When the step runs without graphs it
+    is issued eagerly with ordinary HIP events on the launch stream instead."""
     from nerf_amd import ops
     acc = {}
-
-    def add(evs):
-        for name, lst in evs.items():
-            a = acc.setdefault(name, [0.0, 0, 0.0])
-            for e0, e1, u in lst:
-                a[0] += e0.elapsed_time(e1); a[1] += 1; a[2] += u
-
-    mode = "graph"
     if step_fn.use_graph:
-        try:
-            ops.KERNEL_TIMES, ops.KERNEL_TIMES_IN_GRAPH = {}, True
-            st2 = mk(True)
-            st2.rays_o.copy_(step_fn.rays_o); st2.rays_d.copy_(step_fn.rays_d); st2.target.copy_(step_fn.target)
-            st2.prepare()
-            evs, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
-            if not evs:
-                raise RuntimeError("no event was captured")
+        # Two copies of the graph, so that each carries few stamps (a stamp is a short idle gap; many of them let the
+        # clock recover and the kernels of that replay run faster than in the timed region): one with stamps around
+        # the three large MLP calls only, one with stamps around everything else.
+        big = ("mlp_fwd_train", "mlp_bwd_data", "mlp_bwd_weights")
+        rate = None
+        for names in (big, None):
+            stamper = Stamper(device, names=names)
+            rate = stamper.rate
+            if names is None:
+                class _Rest:          # every call but the large ones
+                    def __contains__(self, n):
+                        return n not in big
+                stamper.names = _Rest()
+            try:
+                ops.KERNEL_TIMES, ops.KERNEL_STAMP = {}, stamper
+                st2 = mk(True)
+                st2.rays_o.copy_(step_fn.rays_o); st2.rays_d.copy_(step_fn.rays_d); st2.target.copy_(step_fn.target)
+                st2.prepare()
+                pairs = ops.KERNEL_TIMES
+            finally:
+                ops.KERNEL_TIMES, ops.KERNEL_STAMP = None, None
+            if not pairs:
+                raise RuntimeError("no call of the step was stamped")
             st2(st2.rays_o, st2.rays_d, st2.target, lr=lr)
             for _ in range(kernel_steps):
                 st2(st2.rays_o, st2.rays_d, st2.target, lr=lr)
                 sync()
-                add(evs)
+                t = stamper.slots.cpu()
+                own = float(t[stamper.pair[1]] - t[stamper.pair[0]])
+                for name, lst in pairs.items():
+                    a = acc.setdefault(name, [0.0, 0, 0.0])
+                    for i0, i1, u in lst:
+                        a[0] += (float(t[i1] - t[i0]) - own) / stamper.rate * 1e3; a[1] += 1; a[2] += u
             del st2
-        except Exception as e:      # noqa: BLE001
-            print("bench.py: in-graph kernel timing unavailable (%s: %s); timing eager launches"
-                  % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
-            mode, acc = "eager", {}
-        finally:
-            ops.KERNEL_TIMES, ops.KERNEL_TIMES_IN_GRAPH = None, False
+        timing = ("one-lane time-stamp kernels (the device's %.0f MHz counter) captured into copies of the step's graph in "
+                  "front of and behind each C-ABI call, on the stream the kernels are launched on, less the distance of two "
+                  "back-to-back stamps; %d replays right after the timed region (one copy stamps the three large MLP calls, "
+                  "another the rest)" % (rate / 1e6, kernel_steps))
     else:
-        mode = "eager"
-    if mode == "eager":
-        was = step_fn.use_graph
-        step_fn.use_graph = False
         step_fn(step_fn.rays_o, step_fn.rays_d, step_fn.target, lr=lr)
         ops.KERNEL_TIMES = {}
         for _ in range(kernel_steps):
             step_fn(step_fn.rays_o, step_fn.rays_d, step_fn.target, lr=lr)
         sync()
         evs, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
-        add(evs)
-        step_fn.use_graph = was
+        for name, lst in evs.items():
+            a = acc.setdefault(name, [0.0, 0, 0.0])
+            for e0, e1, u in lst:
+                a[0] += e0.elapsed_time(e1); a[1] += 1; a[2] += u
+        timing = ("HIP events on the launch stream around each C-ABI call, %d eager steps of the same training step "
+                  "run right after the timed region" % kernel_steps)
     times = {k: (a[0] / a[1], a[1], a[2] / a[1], a[0]) for k, a in acc.items() if a[1]}
-    timing = ("HIP event-record nodes captured into the step's graph in front of and behind each C-ABI call, on the "
-              "stream the kernels are launched on; %d replays of that graph right after the timed region"
-              if mode == "graph" else
-              "HIP events on the launch stream around each C-ABI call, %d eager steps of the same training step run "
-              "right after the timed region") % kernel_steps
     return times, timing
 
 

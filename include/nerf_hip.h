@@ -241,6 +241,44 @@ int nerf_mlp_fp32_pack_segment(const float *w, int rows, int ld, int col0, int c
 int nerf_mlp_fp32_fwd(int64_t M, const float *x_pts, int cp, const float *x_views, int cv,
                       const nerf_fp32_layer_t *layers, int n_layers, float *raw, void *stream);
 
+/* ------------------------------------------------------------------------
+ * fp32 backward -- the autograd of src/nerf_project/models/nerf.py:173-209 with respect to the parameters,
+ * as scripts/train_nerf.py:334-335 runs it in fp32, on v_mfma_f32_32x32x2_f32 for the same layer lists as
+ * nerf_mlp_fp32_fwd.  nerf_mlp_fp32_fwd_train is that forward keeping, in `saved`
+ * (nerf_mlp_fp32_saved_floats(...) floats, 16-byte aligned), the encoded inputs and every hidden layer's output.
+ * nerf_mlp_fp32_bwd then takes d_raw [M,4] and writes every layer's weight and bias gradient:
+ *   1. the backward-data chain dH_in = W^T dZ, dZ = dH * [y > 0], layer by layer in LDS like the forward (it is
+ *      the forward kernel run on the transposed weights), keeping every layer's dZ in the workspace;
+ *   2. per layer segment dW = sum over samples dZ x input^T, the sample axis split over workgroups into fp32
+ *      partial blocks that a second kernel adds up in a fixed order (bitwise reproducible); db = row sums of dZ.
+ * Gradients with respect to the encoded inputs are not produced.
+ * grads: HOST array, one entry per layer of `layers`:
+ *   wt[s]      per segment whose source is a hidden buffer: nerf_mlp_fp32_pack_segment output of the TRANSPOSED
+ *              weight block, i.e. of the [cols[s], out_features] matrix W[:, col0[s] : col0[s] + cols[s]]^T with
+ *              col0 = 0, cols = out_features; for a layer that writes raw (dst = NERF_FP32_DST_RAW) of the
+ *              [cols[s], 4] matrix holding that block in columns dst_col .. and zeros elsewhere.  NULL for a
+ *              segment read from the encoded inputs (no gradient flows there).
+ *   d_weight   [out_features, ld] row-major (the layer's weight gradient, written, not accumulated);
+ *   col0/cols  per segment: the columns of d_weight it owns (cols rounded up to 8 = the layer's k_padded);
+ *   d_bias     [out_features].
+ * workspace: nerf_mlp_fp32_bwd_workspace_floats(...) floats, 16-byte aligned.
+ */
+typedef struct {
+    const float *wt[2];
+    float *d_weight;
+    int ld;
+    int col0[2];
+    int cols[2];
+    float *d_bias;
+} nerf_fp32_grad_t;
+int64_t nerf_mlp_fp32_saved_floats(int64_t M, int cp, int cv, const nerf_fp32_layer_t *layers, int n_layers);
+int64_t nerf_mlp_fp32_bwd_workspace_floats(int64_t M, int cp, int cv, const nerf_fp32_layer_t *layers, int n_layers);
+int nerf_mlp_fp32_fwd_train(int64_t M, const float *x_pts, int cp, const float *x_views, int cv,
+                            const nerf_fp32_layer_t *layers, int n_layers, float *raw, float *saved, void *stream);
+int nerf_mlp_fp32_bwd(int64_t M, int cp, int cv, const nerf_fp32_layer_t *layers, const nerf_fp32_grad_t *grads,
+                      int n_layers, const float *d_raw, const float *saved, float *workspace,
+                      int64_t workspace_floats, void *stream);
+
 /* The same forward as nerf_mlp_fwd_encoded(saved = NULL) with the workspace inside the library.  It has no
  * counterpart in the reference: it exists for callers that cannot allocate device memory -- code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The call allocates nothing
@@ -309,8 +347,9 @@ int nerf_adam_step(int64_t n, float *params, const float *grads, float *exp_avg,
 /* Same update with the hyper-parameters in device memory, so that the call can be captured in a
  * HIP graph and replayed while lr changes: state = device float[8] = {lr, beta1, beta2, eps,
  * grad_scale, step, ticket, scratch}.  The call applies the update of step state[5] + 1 and leaves
- * state[5] advanced by one (it starts from 0); state[6] is a workgroup counter the call clears itself
- * (a 4-byte memset on the stream in front of the kernel) and leaves at 0: callers need not initialise it. */
+ * state[5] advanced by one (it starts from 0); state[6] is a workgroup counter: it MUST be 0 before the
+ * first call (zero-initialise the array) and is 0 again after every call.  With anything else there the
+ * step counter stops advancing and the bias corrections are wrong from then on. */
 int nerf_adam_step_dev(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
                        float *state, void *stream);
 

@@ -54,6 +54,10 @@ _SIGS = {
     "nerf_mlp_fp32_segment_floats": (c_int64, [c_int, c_int]),
     "nerf_mlp_fp32_pack_segment": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "nerf_mlp_fp32_fwd": (c_int, [c_int64, P, c_int, P, c_int, P, c_int, P, P]),
+    "nerf_mlp_fp32_saved_floats": (c_int64, [c_int64, c_int, c_int, P, c_int]),
+    "nerf_mlp_fp32_bwd_workspace_floats": (c_int64, [c_int64, c_int, c_int, P, c_int]),
+    "nerf_mlp_fp32_fwd_train": (c_int, [c_int64, P, c_int, P, c_int, P, c_int, P, P, P]),
+    "nerf_mlp_fp32_bwd": (c_int, [c_int64, c_int, c_int, P, P, c_int, P, P, P, c_int64, P]),
     "nerf_adam_step_dev": (c_int, [c_int64, P, P, P, P, P, P]),
     "nerf_mse_pair": (c_int, [c_int64, P, P, P, P, P, P, P]),
     "nerf_adam_step": (c_int, [c_int64, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
@@ -79,6 +83,12 @@ class Fp32Layer(ctypes.Structure):
     """nerf_fp32_layer_t of include/nerf_hip.h: one layer of the fp32 forward's program."""
     _fields_ = [("weights", c_void_p * 2), ("k_padded", c_int * 2), ("src", c_int * 2), ("n_segments", c_int),
                 ("bias", c_void_p), ("out_features", c_int), ("relu", c_int), ("dst", c_int), ("dst_col", c_int)]
+
+
+class Fp32Grad(ctypes.Structure):
+    """nerf_fp32_grad_t of include/nerf_hip.h: where one layer's gradients go, and its transposed weights."""
+    _fields_ = [("wt", c_void_p * 2), ("d_weight", c_void_p), ("ld", c_int), ("col0", c_int * 2), ("cols", c_int * 2),
+                ("d_bias", c_void_p)]
 
 
 FP32_MAX_WIDTH, FP32_MAX_PTS, FP32_MAX_VIEWS, FP32_MAX_LAYERS = 256, 64, 32, 16

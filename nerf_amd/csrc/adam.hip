@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t n, float* __restrict_
 // One launch: every workgroup derives the bias-corrected factors of step + 1 itself (thread 0, fp64, shared
 // through LDS); the workgroup that finishes last -- told by a ticket counter in state[6], which it resets --
 // advances `step`.  Every workgroup has read `step` before it takes its ticket, so none sees the new value.
-// The entry point clears the ticket on the stream in front of every launch.
+// The ticket must be 0 when the first call is made (the caller zero-initialises `state`); every call leaves it 0.
 __global__ __launch_bounds__(256) void adam_dev_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        float* __restrict__ state) {
@@ -84,9 +84,6 @@ extern "C" int nerf_adam_step_dev(int64_t n, float* params, const float* grads, 
     int64_t blocks = (n + 1023) / 1024;
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;            // n = 0 still counts as a step
-    // the ticket must start at zero whatever an earlier caller or an aborted launch left in state[6]
-    const hipError_t me = hipMemsetAsync(state + 6, 0, sizeof(unsigned), st);
-    if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(nerf::adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, params, grads, exp_avg,
                        exp_avg_sq, state);
     return nerf_launch_status();

@@ -198,7 +198,14 @@ constexpr int64_t PACK_F16_OFF = (PACK_BIAS_OFF + (int64_t)BIAS_FLOATS * 4 + 102
 // with: W_f transposed [in 256][out 256], b_f [256] (exact), W_r0[:, :256] [128][256]
 constexpr int64_t PACK_POST_OFF = PACK_F16_OFF + (int64_t)F16_BLOCKS * BLOCK_BYTES;
 constexpr int POST_WF = 0, POST_BF = 256 * 256, POST_WR0 = POST_BF + 256, POST_FLOATS = POST_WR0 + 128 * 256;
-constexpr int64_t PACK_BYTES = PACK_POST_OFF + (int64_t)POST_FLOATS * 4;
+// One word per workgroup of the pack launch, non-zero when that workgroup met a NaN or an infinity among the
+// parameters it converted.  The forward kernels then replace the biases of the rows that become raw by NaN (see
+// load_bias_table): the reference's torch.relu keeps a NaN (nerf.py:178), so there a non-finite parameter
+// anywhere turns every output and the loss into NaN, whereas the kernels' integer-maximum ReLU would turn the
+// negative-signed NaN an MFMA returns into 0 and hide a diverged network from the loss.
+constexpr int PACK_FLAG_WORDS = 1024;
+constexpr int64_t PACK_FLAGS_OFF = PACK_POST_OFF + (int64_t)POST_FLOATS * 4;
+constexpr int64_t PACK_BYTES = PACK_FLAGS_OFF + (int64_t)PACK_FLAG_WORDS * 4;
 
 // ---- slot maps --------------------------------------------------------------------------------
 __host__ __device__ constexpr int slot_of(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }

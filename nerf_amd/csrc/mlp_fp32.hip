@@ -34,8 +34,18 @@ constexpr int OFF_RED = OFF_HB + BUF_FLOATS_H;      // partial sums of the outpu
 constexpr int LDS_FLOATS = OFF_RED + WAVES * TILE * 4;   // 160 KiB
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 
+// Optional per-layer side channels in global memory, all "transposed": one row of ldm floats per feature,
+// samples along the row (ldm = M rounded up to whole tiles), so that a wave's 32 samples of one feature are one
+// 128-byte run.  The training forward keeps every hidden layer's output and the encoded inputs there; the
+// backward-data chain -- the same kernel run on the transposed weights -- gates its outputs with them
+// (relu'(y) = [y > 0]) and keeps every layer's gradient for the weight-gradient pass.
 struct Program {
     nerf_fp32_layer_t layer[NERF_FP32_MAX_LAYERS];
+    float* save[NERF_FP32_MAX_LAYERS];         // nullable: rows = the layer's output features (after the epilogue)
+    const float* gate[NERF_FP32_MAX_LAYERS];   // nullable: outputs are zeroed where this tensor is <= 0
+    float* save_pts;                           // nullable: the padded input rows as loaded (cp_pad rows)
+    float* save_views;                         // nullable (cv_pad rows)
+    int64_t ldm;
     int n_layers;
 };
 
@@ -47,12 +57,14 @@ __device__ __forceinline__ int buf_off(int id) {
 }
 
 // rows [M][C] fp32 -> LDS [ceil(C/4)*... ][sample][4], zero-padded to cpad features and to the tile
-__device__ __forceinline__ void load_input(float* dst, const float* __restrict__ x, int64_t m0, int64_t M, int C, int cpad) {
+__device__ __forceinline__ void load_input(float* dst, const float* __restrict__ x, int64_t m0, int64_t M, int C, int cpad,
+                                           float* __restrict__ xt, int64_t ldm) {
     for (int idx = threadIdx.x; idx < TILE * cpad; idx += THREADS) {
         const int n = idx / cpad, k = idx - n * cpad;
         const int64_t m = m0 + n;
         const float v = (k < C && m < M) ? x[m * C + k] : 0.0f;
         dst[((k >> 2) * TILE + n) * 4 + (k & 3)] = v;
+        if (xt != nullptr) xt[(int64_t)k * ldm + m] = v;       // (samples past M: zeros, the rows are whole tiles)
     }
 }
 
@@ -111,7 +123,7 @@ __device__ __forceinline__ Head load_head(const Program& prog, int li, int wave,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * ft + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < L.out_features) hd.bias[r] = L.bias[row];
+            if (L.bias != nullptr && row < L.out_features) hd.bias[r] = L.bias[row];
         }
         const int nch = L.k_padded[0] >> 3;
         const f32x4* wf = reinterpret_cast<const f32x4*>(L.weights[0]) + ((size_t)ft * nch) * 64 + lane;
@@ -135,8 +147,8 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
     for (int64_t tile = blockIdx.x; tile * TILE < M; tile += gridDim.x) {
         const int64_t m0 = tile * TILE;
         __syncthreads();                      // the previous tile's readers are done with the buffers
-        load_input(lds + OFF_XP, x_pts, m0, M, cp, cp_pad);
-        if (x_views != nullptr) load_input(lds + OFF_XV, x_views, m0, M, cv, cv_pad);
+        load_input(lds + OFF_XP, x_pts, m0, M, cp, cp_pad, prog.save_pts, prog.ldm);
+        if (x_views != nullptr) load_input(lds + OFF_XV, x_views, m0, M, cv, cv_pad, prog.save_views, prog.ldm);
         __syncthreads();
 
         for (int li = 0; li < prog.n_layers; ++li) {
@@ -195,6 +207,26 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { acc0[r] = relu_keep_nan(acc0[r]); acc1[r] = relu_keep_nan(acc1[r]); }
                 }
+                const float* gate = prog.gate[li];
+                float* save = prog.save[li];
+                if (gate != nullptr || save != nullptr) {
+                    // register r of lane (n, h) is feature 32 ft + 8 (r >> 2) + 4 h + (r & 3) of sample first + n (+ 32)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = 32 * ft + 8 * (r >> 2) + 4 * h + (r & 3);
+                        if (f < L.out_features) {
+                            const int64_t at = (int64_t)f * prog.ldm + m0 + first + n;
+                            if (gate != nullptr) {
+                                if (!(gate[at] > 0.0f)) acc0[r] = 0.0f;
+                                if (!split && !(gate[at + 32] > 0.0f)) acc1[r] = 0.0f;
+                            }
+                            if (save != nullptr) {
+                                save[at] = acc0[r];
+                                if (!split) save[at + 32] = acc1[r];
+                            }
+                        }
+                    }
+                }
                 f32x4* dst = reinterpret_cast<f32x4*>(lds + buf_off(L.dst));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -224,6 +256,113 @@ __global__ __launch_bounds__(256) void pack_segment_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradients of one layer segment: dW[out][in] = sum over samples of dZ[out][m] * X[in][m], both operands in
+// the transposed layout (a row per feature, samples along it), on v_mfma_f32_32x32x2_f32 with the sample as the
+// contraction index.  A workgroup (four waves) owns one 32-row tile of dW over one chunk of the samples; wave w
+// takes the column tiles w, w + 4, w + 8.  Per step of 32 samples a lane loads 16 consecutive samples of its row
+// of each operand (64 bytes) and issues 16 MFMAs per column tile.  Every chunk writes an fp32 partial block;
+// fp32_wgrad_reduce_kernel sums the chunks in index order (bitwise reproducible).  The bias gradient is the row
+// sum of dZ, taken from the A operand by wave 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_MAX_COL_TILES = 3;      // per wave: 4 waves x 3 tiles x 32 = 384 >= 256 + 64 input features
+struct WgradArgs {
+    const float* At;      // dZ, [out rows][ldm]
+    const float* Bt;      // layer input, [in rows][ldm]
+    int64_t ldm;
+    int64_t steps;        // ldm / 32
+    int out, in;
+    int out_pad, in_pad;  // rounded up to 32
+    float* part;          // [chunks][out_pad][in_pad]
+    float* part_bias;     // [chunks][out_pad]
+};
+
+__global__ __launch_bounds__(256) void fp32_wgrad_kernel(const WgradArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, kk = lane >> 5;
+    const int ot = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
+    const int n_it = a.in_pad >> 5;
+    const int64_t per = (a.steps + n_chunks - 1) / n_chunks;
+    const int64_t st0 = chunk * per, st1 = st0 + per < a.steps ? st0 + per : a.steps;
+    f32x16 acc[WG_MAX_COL_TILES];
+#pragma unroll
+    for (int t = 0; t < WG_MAX_COL_TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+    const int rowA = 32 * ot + i;
+    const bool validA = rowA < a.out;
+    const f32x4* pA = reinterpret_cast<const f32x4*>(a.At + (int64_t)(validA ? rowA : 0) * a.ldm + 16 * kk);
+    const f32x4* pB[WG_MAX_COL_TILES];
+    bool validB[WG_MAX_COL_TILES];
+#pragma unroll
+    for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
+        const int rowB = 32 * (wave + 4 * t) + i;
+        validB[t] = (wave + 4 * t) < n_it && rowB < a.in;
+        pB[t] = reinterpret_cast<const f32x4*>(a.Bt + (int64_t)(validB[t] ? rowB : 0) * a.ldm + 16 * kk);
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t st = st0; st < st1; ++st) {
+        const int64_t m4 = st * 8;            // 32 samples = 8 float4
+        f32x4 av[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = validA ? pA[m4 + e] : zero4;
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum += (av[e][0] + av[e][1]) + (av[e][2] + av[e][3]);
+        }
+#pragma unroll
+        for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
+            if (wave + 4 * t >= n_it) continue;          // wave-uniform
+            f32x4 bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = validB[t] ? pB[t][m4 + e] : zero4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e][j], bv[e][j], acc[t], 0, 0, 0);
+        }
+    }
+    // accumulator register r of lane (n = lane & 31, h = lane >> 5): row 8 (r >> 2) + 4 h + (r & 3), column n
+    float* part = a.part + (int64_t)chunk * a.out_pad * a.in_pad;
+#pragma unroll
+    for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
+        if (wave + 4 * t >= n_it) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * ot + 8 * (r >> 2) + 4 * kk + (r & 3);
+            part[(int64_t)row * a.in_pad + 32 * (wave + 4 * t) + i] = acc[t][r];
+        }
+    }
+    if (wave == 0) {
+        const float other = __shfl_xor(bsum, 32);
+        if (kk == 0) a.part_bias[(int64_t)chunk * a.out_pad + rowA] = bsum + other;
+    }
+}
+
+struct WgradReduceArgs {
+    const float* part; const float* part_bias;
+    int n_chunks, out, in, out_pad, in_pad;
+    float* d_weight; int ld, col0;     // d_weight[row * ld + col0 + col]
+    float* d_bias;                     // nullable
+};
+__global__ __launch_bounds__(256) void fp32_wgrad_reduce_kernel(const WgradReduceArgs a) {
+    const int64_t total = (int64_t)a.out * a.in;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const int row = (int)(i / a.in), col = (int)(i - (int64_t)row * a.in);
+        float v = 0.0f;
+        for (int c = 0; c < a.n_chunks; ++c) v += a.part[((int64_t)c * a.out_pad + row) * a.in_pad + col];
+        a.d_weight[(int64_t)row * a.ld + a.col0 + col] = v;
+    } else if (a.d_bias != nullptr && i < total + a.out) {
+        const int row = (int)(i - total);
+        float v = 0.0f;
+        for (int c = 0; c < a.n_chunks; ++c) v += a.part_bias[(int64_t)c * a.out_pad + row];
+        a.d_bias[row] = v;
+    }
+}
+
 }  // namespace fp32
 }  // namespace nerf
 
@@ -246,21 +385,22 @@ extern "C" int nerf_mlp_fp32_pack_segment(const float* w, int rows, int ld, int 
     return nerf_launch_status();
 }
 
-extern "C" int nerf_mlp_fp32_fwd(int64_t M, const float* x_pts, int cp, const float* x_views, int cv,
-                                 const nerf_fp32_layer_t* layers, int n_layers, float* raw, void* stream) {
-    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
-    if (M == 0) return NERF_OK;
-    NERF_REQUIRE(x_pts && layers && raw, NERF_E_NULL);
+// Checks a layer list and copies it into a kernel program.  On success `prod[l][s]` names the layer whose output
+// segment s of layer l reads (-1: encoded points, -2: encoded view directions).
+static int build_program(int cp, int cv, bool have_views, const nerf_fp32_layer_t* layers, int n_layers, Program* prog,
+                         int (*prod)[2]) {
+    NERF_REQUIRE(layers, NERF_E_NULL);
     NERF_REQUIRE(n_layers >= 1 && n_layers <= NERF_FP32_MAX_LAYERS, NERF_E_ARCH);
-    NERF_REQUIRE(cp >= 1 && cp <= MAX_CP && cv >= 0 && cv <= MAX_CV && (x_views != nullptr || cv == 0), NERF_E_ARCH);
-    Program prog;
-    prog.n_layers = n_layers;
+    NERF_REQUIRE(cp >= 1 && cp <= MAX_CP && cv >= 0 && cv <= MAX_CV && (have_views || cv == 0), NERF_E_ARCH);
+    *prog = Program{};
+    prog->n_layers = n_layers;
     // Every index a layer names is checked here: the kernel trusts the program.  `width[b]` is how many
     // features of buffer b hold defined values: the padded input widths, and for a hidden buffer the rows its
     // last writer produced (whole 32-row tiles: rows past out_features come out as zeros).  A layer may not
     // read beyond that, or it would multiply its zero-padded weights with stale LDS contents.
-    int written = (1 << NERF_FP32_BUF_PTS) | (x_views ? 1 << NERF_FP32_BUF_VIEWS : 0);
+    int written = (1 << NERF_FP32_BUF_PTS) | (have_views ? 1 << NERF_FP32_BUF_VIEWS : 0);
     int width[4] = {(cp + 7) & ~7, (cv + 7) & ~7, 0, 0};
+    int live[4] = {-1, -2, -3, -3};
     int raw_cols = 0;
     for (int i = 0; i < n_layers; ++i) {
         const nerf_fp32_layer_t& L = layers[i];
@@ -272,6 +412,7 @@ extern "C" int nerf_mlp_fp32_fwd(int64_t M, const float* x_pts, int cp, const fl
             NERF_REQUIRE(L.src[s] >= NERF_FP32_BUF_PTS && L.src[s] <= NERF_FP32_BUF_B && ((written >> L.src[s]) & 1), NERF_E_ARCH);
             NERF_REQUIRE(L.k_padded[s] >= 8 && L.k_padded[s] % 8 == 0 && L.k_padded[s] <= width[L.src[s]], NERF_E_ARCH);
             NERF_REQUIRE(L.src[s] != L.dst, NERF_E_ARCH);
+            if (prod) prod[i][s] = live[L.src[s]];
         }
         if (L.dst == NERF_FP32_DST_RAW) {
             NERF_REQUIRE(L.dst_col >= 0 && L.dst_col + L.out_features <= 4, NERF_E_ARCH);
@@ -281,12 +422,221 @@ extern "C" int nerf_mlp_fp32_fwd(int64_t M, const float* x_pts, int cp, const fl
             NERF_REQUIRE(L.out_features <= MAX_W, NERF_E_ARCH);
             written |= 1 << L.dst;
             width[L.dst] = (L.out_features + 31) / 32 * 32;
+            live[L.dst] = i;
         }
-        prog.layer[i] = L;
+        prog->layer[i] = L;
     }
     NERF_REQUIRE(raw_cols == 0xf, NERF_E_ARCH);      // the program must write all four columns of raw
+    return NERF_OK;
+}
+
+static inline int64_t fp32_ldm(int64_t M) { return (M + TILE - 1) / TILE * TILE; }
+static inline unsigned fp32_grid(int64_t M) {
     const int64_t n_tiles = (M + TILE - 1) / TILE;
-    const unsigned grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
-    hipLaunchKernelGGL(mlp_fp32_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, M, x_pts, cp, x_views, cv, prog, raw);
+    return (unsigned)(n_tiles < 256 ? n_tiles : 256);
+}
+
+// rows of the saved buffer: encoded points (padded), encoded view directions (padded), then each hidden layer's output
+static int64_t saved_rows(int cp, int cv, const nerf_fp32_layer_t* layers, int n_layers, int64_t* row_of_layer) {
+    int64_t rows = ((cp + 7) & ~7) + ((cv + 7) & ~7);
+    for (int i = 0; i < n_layers; ++i) {
+        if (row_of_layer) row_of_layer[i] = rows;
+        if (layers[i].dst != NERF_FP32_DST_RAW) rows += layers[i].out_features;
+    }
+    return rows;
+}
+
+extern "C" int64_t nerf_mlp_fp32_saved_floats(int64_t M, int cp, int cv, const nerf_fp32_layer_t* layers, int n_layers) {
+    if (M < 0 || !layers || n_layers < 1 || n_layers > NERF_FP32_MAX_LAYERS) return -1;
+    return saved_rows(cp, cv, layers, n_layers, nullptr) * fp32_ldm(M);
+}
+
+// chunks of the sample axis of one weight-gradient launch: enough workgroups to fill the chip, at least four steps each
+static int wgrad_chunks(int64_t steps, int out_tiles) {
+    int64_t c = (512 + out_tiles - 1) / out_tiles;
+    if (c > steps / 4) c = steps / 4;
+    if (c > 64) c = 64;
+    return c < 1 ? 1 : (int)c;
+}
+
+// workspace of nerf_mlp_fp32_bwd: the gradient rows (8 for d_raw, then every hidden layer's output gradient),
+// then the partial blocks of the largest weight-gradient launch
+static int64_t bwd_workspace(int64_t M, const nerf_fp32_layer_t* layers, int n_layers, int64_t* part_off) {
+    const int64_t ldm = fp32_ldm(M);
+    int64_t rows = 8;
+    int64_t part = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const nerf_fp32_layer_t& L = layers[i];
+        if (L.dst != NERF_FP32_DST_RAW) rows += L.out_features;
+        const int out_pad = (L.out_features + 31) / 32 * 32;
+        for (int s = 0; s < L.n_segments; ++s) {
+            const int in_pad = (L.k_padded[s] + 31) / 32 * 32;
+            const int64_t need = (int64_t)wgrad_chunks(ldm / 32, out_pad / 32) * out_pad * (in_pad + 1);
+            if (need > part) part = need;
+        }
+    }
+    const int64_t off = (rows * ldm + 63) / 64 * 64;
+    if (part_off) *part_off = off;
+    return off + part;
+}
+
+extern "C" int64_t nerf_mlp_fp32_bwd_workspace_floats(int64_t M, int cp, int cv, const nerf_fp32_layer_t* layers, int n_layers) {
+    (void)cp; (void)cv;
+    if (M < 0 || !layers || n_layers < 1 || n_layers > NERF_FP32_MAX_LAYERS) return -1;
+    return bwd_workspace(M, layers, n_layers, nullptr);
+}
+
+static int fp32_forward(int64_t M, const float* x_pts, int cp, const float* x_views, int cv, const nerf_fp32_layer_t* layers,
+                        int n_layers, float* raw, float* saved, void* stream) {
+    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
+    if (M == 0) return NERF_OK;
+    NERF_REQUIRE(x_pts && layers && raw, NERF_E_NULL);
+    Program prog;
+    const int rc = build_program(cp, cv, x_views != nullptr, layers, n_layers, &prog, nullptr);
+    if (rc) return rc;
+    prog.ldm = fp32_ldm(M);
+    if (saved != nullptr) {
+        NERF_REQUIRE(nerf_aligned(saved, 16), NERF_E_ALIGN);
+        int64_t row[NERF_FP32_MAX_LAYERS];
+        saved_rows(cp, cv, layers, n_layers, row);
+        prog.save_pts = saved;
+        prog.save_views = x_views ? saved + (int64_t)((cp + 7) & ~7) * prog.ldm : nullptr;
+        for (int i = 0; i < n_layers; ++i)
+            if (layers[i].dst != NERF_FP32_DST_RAW) prog.save[i] = saved + row[i] * prog.ldm;
+    }
+    hipLaunchKernelGGL(mlp_fp32_kernel, dim3(fp32_grid(M)), dim3(THREADS), 0, (hipStream_t)stream, M, x_pts, cp, x_views, cv, prog, raw);
     return nerf_launch_status();
+}
+
+extern "C" int nerf_mlp_fp32_fwd(int64_t M, const float* x_pts, int cp, const float* x_views, int cv,
+                                 const nerf_fp32_layer_t* layers, int n_layers, float* raw, void* stream) {
+    return fp32_forward(M, x_pts, cp, x_views, cv, layers, n_layers, raw, nullptr, stream);
+}
+
+extern "C" int nerf_mlp_fp32_fwd_train(int64_t M, const float* x_pts, int cp, const float* x_views, int cv,
+                                       const nerf_fp32_layer_t* layers, int n_layers, float* raw, float* saved, void* stream) {
+    NERF_REQUIRE(saved != nullptr || M == 0, NERF_E_NULL);
+    return fp32_forward(M, x_pts, cp, x_views, cv, layers, n_layers, raw, saved, stream);
+}
+
+extern "C" int nerf_mlp_fp32_bwd(int64_t M, int cp, int cv, const nerf_fp32_layer_t* layers, const nerf_fp32_grad_t* grads,
+                                 int n_layers, const float* d_raw, const float* saved, float* workspace,
+                                 int64_t workspace_floats, void* stream) {
+    NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
+    NERF_REQUIRE(layers && grads, NERF_E_NULL);
+    Program fwd;
+    int prod[NERF_FP32_MAX_LAYERS][2];
+    int rc = build_program(cp, cv, cv > 0, layers, n_layers, &fwd, prod);
+    if (rc) return rc;
+    for (int c = 0; c < n_layers; ++c) {
+        const nerf_fp32_layer_t& L = layers[c];
+        const nerf_fp32_grad_t& G = grads[c];
+        NERF_REQUIRE(G.d_weight && G.d_bias, NERF_E_NULL);
+        int total = 0;
+        for (int s = 0; s < L.n_segments; ++s) {
+            NERF_REQUIRE(G.cols[s] >= 1 && ((G.cols[s] + 7) & ~7) == L.k_padded[s] && G.col0[s] >= 0, NERF_E_ARCH);
+            NERF_REQUIRE(G.col0[s] + G.cols[s] <= G.ld, NERF_E_ARCH);
+            NERF_REQUIRE(prod[c][s] < 0 || (G.wt[s] != nullptr && nerf_aligned(G.wt[s], 16)), NERF_E_NULL);
+            total += G.cols[s];
+        }
+        NERF_REQUIRE(total <= G.ld, NERF_E_ARCH);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {       // no samples: zero gradients
+        for (int c = 0; c < n_layers; ++c) {
+            hipError_t e = hipMemsetAsync(grads[c].d_weight, 0, sizeof(float) * layers[c].out_features * grads[c].ld, st);
+            if (e == hipSuccess) e = hipMemsetAsync(grads[c].d_bias, 0, sizeof(float) * layers[c].out_features, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return NERF_OK;
+    }
+    NERF_REQUIRE(d_raw && saved && workspace, NERF_E_NULL);
+    NERF_REQUIRE(nerf_aligned(saved, 16) && nerf_aligned(workspace, 16), NERF_E_ALIGN);
+    int64_t part_off = 0;
+    NERF_REQUIRE(workspace_floats >= bwd_workspace(M, layers, n_layers, &part_off), NERF_E_WORKSPACE);
+    const int64_t ldm = fp32_ldm(M);
+    const int cp_pad = (cp + 7) & ~7;
+    int64_t yrow[NERF_FP32_MAX_LAYERS];
+    saved_rows(cp, cv, layers, n_layers, yrow);
+    // gradient rows in the workspace: d_raw transposed (8 rows, written by the chain's input load), then dZ of every hidden layer
+    int64_t zrow[NERF_FP32_MAX_LAYERS];
+    {
+        int64_t r = 8;
+        for (int c = 0; c < n_layers; ++c) {
+            if (layers[c].dst == NERF_FP32_DST_RAW) zrow[c] = layers[c].dst_col;
+            else { zrow[c] = r; r += layers[c].out_features; }
+        }
+    }
+    // ---- 1. backward-data chain: the forward kernel on the transposed weights, hidden tensors in reverse order ----
+    // The gradient of a hidden layer p's output lives in the LDS buffer its output lived in.  It is the sum over the
+    // layers c that read that output of W_c[:, segment]^T dZ_c, where dZ_c is in c's own buffer -- or, for an output
+    // layer, in the input buffer that holds d_raw -- gated by [y_p > 0] when p has a ReLU.
+    Program chain{};
+    chain.ldm = ldm;
+    chain.save_pts = workspace;
+    int n_chain = 0;
+    for (int p = n_layers - 1; p >= 0; --p) {
+        const nerf_fp32_layer_t& P = layers[p];
+        if (P.dst == NERF_FP32_DST_RAW) continue;
+        nerf_fp32_layer_t C{};
+        for (int c = p + 1; c < n_layers; ++c)
+            for (int s = 0; s < layers[c].n_segments; ++s) {
+                if (prod[c][s] != p) continue;
+                NERF_REQUIRE(C.n_segments < 2, NERF_E_ARCH);       // at most two readers of one hidden tensor
+                const bool out_layer = layers[c].dst == NERF_FP32_DST_RAW;
+                C.weights[C.n_segments] = grads[c].wt[s];
+                C.k_padded[C.n_segments] = out_layer ? 8 : (layers[c].out_features + 7) & ~7;
+                C.src[C.n_segments] = out_layer ? NERF_FP32_BUF_PTS : layers[c].dst;
+                ++C.n_segments;
+            }
+        float* dz = workspace + zrow[p] * ldm;
+        if (C.n_segments == 0) {       // nobody reads this layer: its gradient is zero
+            const hipError_t e = hipMemsetAsync(dz, 0, sizeof(float) * P.out_features * ldm, st);
+            if (e != hipSuccess) return (int)e;
+            continue;
+        }
+        NERF_REQUIRE(n_chain < NERF_FP32_MAX_LAYERS, NERF_E_ARCH);
+        C.bias = nullptr; C.out_features = P.out_features; C.relu = 0; C.dst = P.dst; C.dst_col = 0;
+        chain.layer[n_chain] = C;
+        chain.gate[n_chain] = P.relu ? saved + yrow[p] * ldm : nullptr;
+        chain.save[n_chain] = dz;
+        ++n_chain;
+    }
+    chain.n_layers = n_chain;
+    // (with no hidden layer at all the kernel still runs its input load, which writes d_raw transposed)
+    hipLaunchKernelGGL(mlp_fp32_kernel, dim3(fp32_grid(M)), dim3(THREADS), 0, st, M, d_raw, 4, (const float*)nullptr, 0, chain,
+                       (float*)nullptr);
+    rc = nerf_launch_status();
+    if (rc) return rc;
+    // ---- 2. weight gradients, one launch pair per layer segment ----
+    float* part = workspace + part_off;
+    for (int c = 0; c < n_layers; ++c) {
+        const nerf_fp32_layer_t& L = layers[c];
+        const nerf_fp32_grad_t& G = grads[c];
+        for (int s = 0; s < L.n_segments; ++s) {
+            WgradArgs w{};
+            w.At = workspace + zrow[c] * ldm;
+            w.Bt = prod[c][s] == -1 ? saved : prod[c][s] == -2 ? saved + (int64_t)cp_pad * ldm : saved + yrow[prod[c][s]] * ldm;
+            w.ldm = ldm; w.steps = ldm / 32;
+            w.out = L.out_features; w.in = G.cols[s];
+            w.out_pad = (w.out + 31) / 32 * 32; w.in_pad = (L.k_padded[s] + 31) / 32 * 32;
+            NERF_REQUIRE(w.in_pad / 32 <= 4 * WG_MAX_COL_TILES, NERF_E_ARCH);
+            const int chunks = wgrad_chunks(w.steps, w.out_pad / 32);
+            w.part = part;
+            w.part_bias = part + (int64_t)chunks * w.out_pad * w.in_pad;
+            hipLaunchKernelGGL(fp32_wgrad_kernel, dim3(w.out_pad / 32, chunks), dim3(256), 0, st, w);
+            rc = nerf_launch_status();
+            if (rc) return rc;
+            WgradReduceArgs r{};
+            r.part = w.part; r.part_bias = w.part_bias; r.n_chunks = chunks; r.out = w.out; r.in = w.in;
+            r.out_pad = w.out_pad; r.in_pad = w.in_pad;
+            r.d_weight = G.d_weight; r.ld = G.ld; r.col0 = G.col0[s];
+            r.d_bias = s == 0 ? G.d_bias : nullptr;
+            const int64_t outputs = (int64_t)w.out * w.in + w.out;
+            hipLaunchKernelGGL(fp32_wgrad_reduce_kernel, dim3((unsigned)((outputs + 255) / 256)), dim3(256), 0, st, r);
+            rc = nerf_launch_status();
+            if (rc) return rc;
+        }
+    }
+    return NERF_OK;
 }

@@ -180,11 +180,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
     const int lane_off = c * 32 + h * 16;        // byte offset of this lane's fragment in a saved unit
 #endif
 
-    {   // bias table -> LDS (plain loads, before any LDS-DMA is in flight)
-        const float* bg = reinterpret_cast<const float*>(a.packed + PACK_BIAS_OFF);
-        for (int i = threadIdx.x; i < BIAS_FLOATS; i += CHAIN_THREADS) bias_lds[i] = bg[i];
-    }
-    __syncthreads();
+    load_bias_table<VIEW>(bias_lds, a.packed);       // (and the check for non-finite parameters)
 
     Ring ring;
     ring_init(ring, lds, a.packed + PACK_FWD_OFF, VIEW ? FWD_CHUNKS : NV_FWD_CHUNKS, lane, wave);

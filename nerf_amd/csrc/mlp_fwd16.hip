@@ -118,11 +118,7 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
 
-    {   // bias table -> LDS (plain loads, before any LDS-DMA is in flight)
-        const float* bg = reinterpret_cast<const float*>(a.packed + PACK_BIAS_OFF);
-        for (int i = threadIdx.x; i < BIAS_FLOATS; i += CHAIN_THREADS) bias_lds[i] = bg[i];
-    }
-    __syncthreads();
+    load_bias_table<VIEW>(bias_lds, a.packed);       // (and the check for non-finite parameters)
 
     Ring ring;
     ring_init(ring, lds, a.packed + PACK_F16_OFF, VIEW ? F16_CHUNKS : NV_F16_CHUNKS, lane, wave);

@@ -132,6 +132,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
     constexpr int64_t E_BWD = NF, E_BIAS = NF + NB, E_F16 = E_BIAS + BIAS_FLOATS, E_POST = E_F16 + N16;
     constexpr int64_t total = E_POST + POST_FLOATS;
     const bool train = streams & NERF_PACK_TRAIN, infer = streams & NERF_PACK_INFER;
+    // a NaN or an infinity among the values this thread converts (every parameter passes through the forward or
+    // the inference stream and the bias table): reported per workgroup in the flag words behind the streams
+    bool bad = false;
+    auto seen = [&](float w) { bad |= !(fabsf(w) <= 3.4028234663852886e38f); return w; };
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * blockDim.x) {
         if (e < E_BWD) {
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
                 const int ks = b - fwd_block0(8);             // one 32-row tile, 16 k-steps in order
                 if (ks < 16) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = (T)nv_out_weight(P, lane & 31, slot_of(ks, lane >> 5, j));
+                    for (int j = 0; j < 8; ++j) f[j] = (T)seen(nv_out_weight(P, lane & 31, slot_of(ks, lane >> 5, j)));
                 }
             } else if (b >= FWD_PAD && b < FWD_BLOCKS_REAL) {
                 b -= FWD_PAD;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
                 const int m = stream_tile(FWD_TILES[L], FWD_KS[L], b), ks = stream_ks(FWD_TILES[L], FWD_KS[L], b);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    f[j] = (T)fwd_weight(P, L, 32 * m + (lane & 31), ks, slot_of(ks, lane >> 5, j));
+                    f[j] = (T)seen(fwd_weight(P, L, 32 * m + (lane & 31), ks, slot_of(ks, lane >> 5, j)));
             }
             fwd[e] = f;
         } else if (e < E_BIAS) {
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
         } else if (e < E_F16) {
             const int i = (int)(e - E_BIAS);
             const int L = i / BIAS_STRIDE, row = i % BIAS_STRIDE;
-            bias[i] = (noview && L >= 8) ? ((L == 8 && row < 4) ? P[OFF_BO + row] : 0.0f) : bias_value(P, L, row);
+            bias[i] = seen((noview && L >= 8) ? ((L == 8 && row < 4) ? P[OFF_BO + row] : 0.0f) : bias_value(P, L, row));
         } else if (e < E_POST) {
             if (!infer) continue;
             const int64_t ef = e - E_F16;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
                 const int ks = b - f16_block0(8);             // one 16-row tile, 8 k-steps in order
                 if (ks < 8 && (lane & 15) < 4) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = (T)nv_out_weight(P, lane & 15, slot16(ks, lane >> 4, j));
+                    for (int j = 0; j < 8; ++j) f[j] = (T)seen(nv_out_weight(P, lane & 15, slot16(ks, lane >> 4, j)));
                 }
             } else if (b >= F16_PAD && b < F16_BLOCKS_REAL) {
                 b -= F16_PAD;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
                 const int rows = L < 8 ? 256 : (L == 8 ? 257 : (L == 9 ? 128 : 3));
                 if (row < rows) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = (T)f16_weight(P, L, row, ks, lane >> 4, j);
+                    for (int j = 0; j < 8; ++j) f[j] = (T)seen(f16_weight(P, L, row, ks, lane >> 4, j));
                 }
             }
             f16[ef] = f;
@@ -233,6 +237,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs args) {
             post[i] = v;
         }
     }
+    const int any = __syncthreads_or(bad);
+    if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(out + PACK_FLAGS_OFF)[blockIdx.x] = any ? 1u : 0u;
 }
 
 }  // namespace mlp
@@ -253,7 +259,7 @@ extern "C" int nerf_mlp_pack_multi(int n_nets, const float* const* params, int p
         NERF_REQUIRE(nerf_aligned(packed[n], 256), NERF_E_ALIGN);
         a.params[n] = params[n]; a.out[n] = (char*)packed[n]; a.streams[n] = streams[n];
     }
-    const dim3 grid(1024, n_nets), block(256);
+    const dim3 grid(nerf::mlp::PACK_FLAG_WORDS, n_nets), block(256);      // one flag word per workgroup
     if (precision == NERF_PREC_BF16)
         hipLaunchKernelGGL(nerf::mlp::pack_kernel<NERF_PREC_BF16>, grid, block, 0, (hipStream_t)stream, a);
     else

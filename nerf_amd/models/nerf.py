@@ -200,10 +200,11 @@ class NeRF(nn.Module):
         key = None if training else ("fp32",) + tuple((p.data_ptr(), p._version) for p in ps)
         if not training and key == self._pack_key and self._fp32_prog is not None:
             return self._fp32_prog
-        keep, layers = [], []
+        keep, layers, spec = [], [], []
         pad8 = lambda v: (v + 7) // 8 * 8
 
         def add(lin, segments, relu, dst, dst_col=0):
+            spec.append((lin, segments, dst, dst_col))
             L = _C.Fp32Layer()
             L.n_segments = len(segments)
             for s, (col0, cols, src) in enumerate(segments):
@@ -233,10 +234,34 @@ class NeRF(nn.Module):
             else:
                 add(self.output_linear, [(0, W, cur)], False, _C.FP32_DST_RAW, 0)
         arr = (_C.Fp32Layer * len(layers))(*layers)
-        self._fp32_prog = (arr, keep)
+        self._fp32_prog = (arr, keep, spec)
         if not training:
             self._pack_key = key
         return self._fp32_prog
+
+    @staticmethod
+    def _fp32_transposed_weights(spec):
+        """Per layer and segment of ``spec`` (from ``_fp32_program``) the packed TRANSPOSED weight block the
+        backward-data chain multiplies with, or None for a segment read from the encoded inputs (nothing flows back
+        there): the [cols, out] matrix W[:, col0:col0+cols]^T, for a layer that writes raw placed in columns
+        dst_col.. of a [cols, 4] matrix (the chain reads d_raw [M, 4] as that layer's output gradient)."""
+        out = []
+        with torch.no_grad():
+            for lin, segments, dst, dst_col in spec:
+                per_seg = []
+                for col0, cols, src in segments:
+                    if src in (_C.FP32_BUF_PTS, _C.FP32_BUF_VIEWS):
+                        per_seg.append(None)
+                        continue
+                    wt = lin.weight.detach()[:, col0:col0 + cols].t()
+                    if dst == _C.FP32_DST_RAW:
+                        full = torch.zeros((cols, 4), dtype=torch.float32, device=wt.device)
+                        full[:, dst_col:dst_col + lin.out_features] = wt
+                        per_seg.append(ops.fp32_pack_segment(full, 0, 4))
+                    else:
+                        per_seg.append(ops.fp32_pack_segment(wt.contiguous(), 0, lin.out_features))
+                out.append(per_seg)
+        return out
 
     def _forward_fp32(self, x_pts_encoded: torch.Tensor, x_views_encoded: Optional[torch.Tensor]) -> torch.Tensor:
         """fp32 evaluation of nerf.py:173-209 (validation mode, any architecture): the fp32 MFMA kernel
@@ -252,7 +277,8 @@ class NeRF(nn.Module):
         lead = x_pts_encoded.shape[:-1]
         xp = x_pts_encoded.reshape(-1, self.input_ch_pts)
         xv = None if x_views_encoded is None else x_views_encoded.reshape(-1, self.input_ch_views)
-        raw = _Fp32Forward.apply(self, xp, xv, *self.ordered_params())
+        want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        raw = _Fp32Forward.apply(self, xp, xv, want_grad, *self.ordered_params())
         return raw.view(*lead, 4)
 
     def _forward_library(self, x_pts_encoded, x_views_encoded, params) -> torch.Tensor:
@@ -276,25 +302,56 @@ class NeRF(nn.Module):
 
 
 class _Fp32Forward(torch.autograd.Function):
-    """Forward: the fp32 MFMA kernel.  Backward: the layers are evaluated again with library GEMMs under
-    autograd and differentiated there (the validation mode's gradients are fp32 library arithmetic)."""
+    """Forward and parameter gradients: the fp32 MFMA kernels of this library (nerf_mlp_fp32_fwd_train keeps the
+    activations, nerf_mlp_fp32_bwd runs the backward-data chain and the weight-gradient contractions).  Only when
+    a gradient with respect to the encoded inputs is asked for -- which the reference's scripts never do -- are
+    the layers evaluated again with library GEMMs under autograd and differentiated there."""
 
     @staticmethod
-    def forward(ctx, model, x_pts, x_views, *params):
-        layers, _keep = model._fp32_program()
-        raw = ops.fp32_mlp_forward(x_pts, x_views, layers)
+    def forward(ctx, model, x_pts, x_views, want_grad, *params):
+        layers, _keep, spec = model._fp32_program()
         ctx.model = model
         ctx.has_views = x_views is not None
-        ctx.save_for_backward(x_pts, *([x_views] if x_views is not None else []), *params)
+        need_inputs = ctx.needs_input_grad[1] or (x_views is not None and ctx.needs_input_grad[2])
+        # (needs_input_grad is set for parameters under no_grad as well: the caller says whether a graph is recorded)
+        ctx.kernel_backward = want_grad and any(ctx.needs_input_grad[4:]) and not need_inputs
+        if ctx.kernel_backward:
+            raw, ctx.acts = ops.fp32_mlp_forward_train(x_pts, x_views, layers)
+            ctx.layers, ctx.keep, ctx.spec = layers, _keep, spec
+            ctx.wt = NeRF._fp32_transposed_weights(spec)       # of the weights this forward used
+            ctx.param_ids = [id(p) for p in model.ordered_params()]
+            ctx.M, ctx.cp = x_pts.shape[0], x_pts.shape[1]
+            ctx.cv = x_views.shape[1] if x_views is not None else 0
+        else:
+            raw = ops.fp32_mlp_forward(x_pts, x_views, layers)
+            ctx.save_for_backward(x_pts, *([x_views] if x_views is not None else []), *params)
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
+        if ctx.kernel_backward:
+            n_par = len(ctx.param_ids)
+            grads_out = [None] * n_par
+            arr = (_C.Fp32Grad * len(ctx.spec))()
+            hold = []
+            for G, (lin, segments, _dst, _dst_col), wts in zip(arr, ctx.spec, ctx.wt):
+                dw, db = torch.empty_like(lin.weight), torch.empty_like(lin.bias)
+                hold += [dw, db]
+                G.d_weight, G.d_bias, G.ld = dw.data_ptr(), db.data_ptr(), lin.in_features
+                for s, ((col0, cols, _src), wt) in enumerate(zip(segments, wts)):
+                    G.col0[s], G.cols[s] = col0, cols
+                    G.wt[s] = None if wt is None else wt.data_ptr()
+                grads_out[ctx.param_ids.index(id(lin.weight))] = dw
+                grads_out[ctx.param_ids.index(id(lin.bias))] = db
+            ops.fp32_mlp_backward(ctx.M, ctx.cp, ctx.cv, ctx.layers, arr, d_raw.reshape(ctx.M, 4), ctx.acts)
+            ctx.acts = None
+            need = ctx.needs_input_grad[4:]
+            return (None, None, None, None, *[g if n else None for g, n in zip(grads_out, need)])
         saved = ctx.saved_tensors
         x_pts = saved[0]
         x_views = saved[1] if ctx.has_views else None
         params = saved[2 if ctx.has_views else 1:]
-        need = list(ctx.needs_input_grad[1:])          # x_pts, x_views, params...
+        need = list(ctx.needs_input_grad[1:3]) + list(ctx.needs_input_grad[4:])          # x_pts, x_views, params...
         with torch.enable_grad():
             xp = x_pts.detach().requires_grad_(need[0])
             xv = None if x_views is None else x_views.detach().requires_grad_(need[1])
@@ -303,7 +360,7 @@ class _Fp32Forward(torch.autograd.Function):
             wanted = [t for t, n in zip([xp, xv] + ps, need) if n and t is not None]
             got = iter(torch.autograd.grad(raw, wanted, d_raw.contiguous(), allow_unused=True)) if wanted else iter(())
         out = [next(got) if (n and t is not None) else None for t, n in zip([xp, xv] + ps, need)]
-        return (None, *out)
+        return (None, out[0], out[1], None, *out[2:])
 
 
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, N_samples: int, det: bool = False, *,

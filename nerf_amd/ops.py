@@ -39,10 +39,13 @@ def _stream(dev: torch.device):
 # Optional per-kernel timing with events on the launch stream (used by bench.py for the roofline
 # figure).  KERNEL_TIMES maps a kernel name to a list of (start_event, end_event, units).
 KERNEL_TIMES = None
-# True: only calls made while the stream is being captured into a HIP graph are recorded, with events that
-# become record nodes of the graph ("external" events), so that every replay of the graph stamps them and
-# elapsed_time() between a pair is the duration inside the replayed step.
-KERNEL_TIMES_IN_GRAPH = False
+# A callable(stream) -> int, or None.  When set, only calls made while the stream is being captured into a HIP
+# graph are recorded (those whose name is in its ``names`` attribute, when it has one): the callable enqueues a
+# time-stamp kernel on the capture stream and returns the index of the slot it writes, so that every replay of the
+# graph stamps the slots and the difference of a pair is the duration inside the replayed step (bench.py owns the
+# kernel and the slots; ordinary HIP events cannot be recorded into a captured graph on ROCm).  KERNEL_TIMES then
+# holds (slot before, slot after, units).
+KERNEL_STAMP = None
 
 
 class _timed:
@@ -53,17 +56,23 @@ class _timed:
     def __enter__(self):
         if KERNEL_TIMES is None:
             return
-        capturing = torch.cuda.is_current_stream_capturing()
-        if KERNEL_TIMES_IN_GRAPH and not capturing:
+        if KERNEL_STAMP is not None:
+            names = getattr(KERNEL_STAMP, "names", None)
+            if torch.cuda.is_current_stream_capturing() and (names is None or self.name in names):
+                self.on = True
+                self.e0 = KERNEL_STAMP(torch.cuda.current_stream(self.dev))
             return
         self.on = True
-        self.e0 = torch.cuda.Event(enable_timing=True, external=capturing)
-        self.e1 = torch.cuda.Event(enable_timing=True, external=capturing)
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
         self.e0.record(torch.cuda.current_stream(self.dev))
 
     def __exit__(self, *exc):
         if self.on:
-            self.e1.record(torch.cuda.current_stream(self.dev))
+            if KERNEL_STAMP is not None:
+                self.e1 = KERNEL_STAMP(torch.cuda.current_stream(self.dev))
+            else:
+                self.e1.record(torch.cuda.current_stream(self.dev))
             KERNEL_TIMES.setdefault(self.name, []).append((self.e0, self.e1, self.units))
         return False
 
@@ -588,6 +597,44 @@ def fp32_mlp_forward(x_pts: torch.Tensor, x_views: Optional[torch.Tensor], layer
     return raw
 
 
+def fp32_mlp_forward_train(x_pts: torch.Tensor, x_views: Optional[torch.Tensor], layers):
+    """``fp32_mlp_forward`` that also keeps the encoded inputs and every hidden layer's output for
+    ``fp32_mlp_backward``: returns (raw [M, 4], saved)."""
+    xp = _gpu_f32(x_pts, "x_pts_encoded")
+    M, cp = xp.shape
+    xv, cv = None, 0
+    if x_views is not None:
+        xv = _gpu_f32(x_views, "x_views_encoded")
+        if xv.shape[0] != M:
+            raise ValueError("x_pts_encoded and x_views_encoded must have the same number of rows")
+        cv = xv.shape[1]
+    lp = ctypes.cast(layers, ctypes.c_void_p)
+    n_saved = int(lib.nerf_mlp_fp32_saved_floats(M, cp, cv, lp, len(layers)))
+    if n_saved < 0:
+        raise ValueError("fp32_mlp_forward_train: bad layer list")
+    raw = torch.empty((M, 4), dtype=torch.float32, device=xp.device)
+    saved = torch.empty((max(n_saved, 4),), dtype=torch.float32, device=xp.device)
+    with torch.cuda.device(xp.device), _timed("mlp_fwd_fp32_train", xp.device, M):
+        check(lib.nerf_mlp_fp32_fwd_train(M, _p(xp), cp, _p(xv), cv, lp, len(layers), _p(raw), _p(saved), _stream(xp.device)),
+              "nerf_mlp_fp32_fwd_train")
+    return raw, saved
+
+
+def fp32_mlp_backward(M: int, cp: int, cv: int, layers, grads, d_raw: torch.Tensor, saved: torch.Tensor) -> None:
+    """Weight and bias gradients of the network ``layers`` describes into the tensors ``grads`` (a ctypes array of
+    ``_C.Fp32Grad``) points to, from ``d_raw`` [M, 4] and what ``fp32_mlp_forward_train`` kept."""
+    d_raw = _gpu_f32(d_raw, "d_raw")
+    if tuple(d_raw.shape) != (M, 4):
+        raise ValueError(f"d_raw must be [{M}, 4], got {tuple(d_raw.shape)}")
+    dev = d_raw.device
+    lp, gp = ctypes.cast(layers, ctypes.c_void_p), ctypes.cast(grads, ctypes.c_void_p)
+    n_work = int(lib.nerf_mlp_fp32_bwd_workspace_floats(M, cp, cv, lp, len(layers)))
+    work = torch.empty((max(n_work, 4),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed("mlp_bwd_fp32", dev, M):
+        check(lib.nerf_mlp_fp32_bwd(M, cp, cv, lp, gp, len(layers), _p(d_raw), _p(saved), _p(work), work.numel(), _stream(dev)),
+              "nerf_mlp_fp32_bwd")
+
+
 # ---------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------
@@ -609,7 +656,7 @@ def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, 
 def adam_step_dev(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                   state: torch.Tensor) -> None:
     """Adam with hyper-parameters in the device tensor ``state`` = [lr, beta1, beta2, eps, grad_scale, step, ticket, -]
-    (the call clears the ticket itself)."""
+    (the ticket, a workgroup counter, must be 0 before the first call; every call leaves it 0)."""
     for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),
                   (state, "state")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):

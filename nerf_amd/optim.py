@@ -75,7 +75,7 @@ class FlatAdam:
     # -- device-resident hyper-parameters (HIP-graph friendly) -----------------------------------------
     def device_state(self) -> torch.Tensor:
         """[lr, beta1, beta2, eps, grad_scale, step, ticket, -] on the GPU, created on first use (slot 6 is the
-        update kernel's workgroup counter: ``nerf_adam_step_dev`` clears it in front of every launch)."""
+        update kernel's workgroup counter: it must be 0 before the first step and every step leaves it 0)."""
         if getattr(self, "_dev_state", None) is None:
             b1, b2 = self.betas
             self._dev_state = torch.tensor([self.param_groups[0]["lr"], b1, b2, self.eps, 1.0, float(self.steps), 0.0,

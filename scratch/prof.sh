@@ -2,10 +2,10 @@
 # rocprofv3 passes over a short bench run: scratch/prof.sh <tag>  -> gpurun_out/prof_<tag>/
 # (kernel trace + stats, then three counter passes, each in a run of its own)
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
-B="python3 bench.py --steps 10 --warmup 3 --repeats 1 --big-batch 0 --no-default-flags --no-cpu-baseline --no-one-eighth --kernel-steps 2"
+B="python3 bench.py --steps 10 --warmup 3 --repeats 1 --big-batch 0 --no-default-flags --no-cpu-baseline --no-one-eighth --kernel-steps 4"
 echo "$B" > $O/command.txt
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/trace_bench.json 2> $O/trace.err
 echo "trace done"

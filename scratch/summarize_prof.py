@@ -80,6 +80,48 @@ with open(os.path.join(dst, "mfma_util.txt"), "w") as f:
         f.write(line + "\n")
 
 bench = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
+
+# ---- the training step's kernels inside the replayed graphs, from the per-dispatch trace -----------------------
+# Dispatches of one kernel in time order: bench.py's first TrainStep issues 2 eager warm-up steps on a side
+# stream, then replays (warmup + steps) graphs -- the timed region; its second, time-stamped TrainStep issues 2
+# eager warm-ups and replays 1 + kernel_steps graphs.  Two networks per step: 2 dispatches per step and kernel.
+try:
+    import shlex
+    a = shlex.split(cmd)
+    getopt = lambda name, default: int(a[a.index(name) + 1]) if name in a else default   # noqa: E731
+    n_timed = getopt("--warmup", 10) + getopt("--steps", 50) * getopt("--repeats", 3)
+    n_stamped = 1 + getopt("--kernel-steps", 10)
+    trace = collections.defaultdict(list)
+    for r in csv.DictReader(open(find("trace", "kernel_trace.csv"))):
+        trace[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    step_kernels = ["mlp_fwd_kernel<0, true, false, true>", "mlp_dgrad_kernel<0, true>", "mlp_wgrad_kernel<0>",
+                    "mlp_reduce_kernel", "mlp_post_kernel"]
+    with open(os.path.join(dst, "step_kernels.txt"), "w") as f:
+        f.write(f"# from the per-dispatch kernel trace of: {cmd}\n")
+        f.write("# average duration (us) of the training step's MLP kernels over both networks, split by how the dispatch was issued:\n")
+        f.write(f"#   timed   = the {n_timed} graph replays of the timed region and its warm-up\n")
+        f.write(f"#   stamped = the {n_stamped} replays of the copy of the graph that carries bench.py's time-stamp kernels\n")
+        f.write("#   eager   = the 2 + 2 warm-up steps issued one by one before the two captures\n")
+        f.write(f"{'kernel':60s} {'timed':>9s} {'stamped':>9s} {'eager':>9s}\n")
+        sums = {"timed": 0.0, "stamped": 0.0}
+        for kn in step_kernels:
+            k = [x for x in trace if kn in x]
+            if not k:
+                continue
+            d = [(e - s0) / 1e3 for s0, e in sorted(trace[k[0]])]
+            e1, t, e2, st = d[:4], d[4:4 + 2 * n_timed], d[4 + 2 * n_timed:8 + 2 * n_timed], d[8 + 2 * n_timed:8 + 2 * n_timed + 2 * n_stamped]
+            avg = lambda v: sum(v) / len(v) if v else float("nan")   # noqa: E731
+            f.write(f"{k[0][:60]:60s} {avg(t):9.1f} {avg(st):9.1f} {avg(e1 + e2):9.1f}\n")
+            if any(x in kn for x in ("wgrad", "reduce", "post")):
+                sums["timed"] += avg(t); sums["stamped"] += avg(st)
+        f.write(f"{'weight-gradient call (wgrad + reduce + post)':60s} {sums['timed']:9.1f} {sums['stamped']:9.1f}\n")
+        rl = bench.get("roofline", {})
+        f.write(f"# bench.py reported for the same run: roofline.kernel {rl.get('kernel')} avg_launch_us {rl.get('avg_launch_us')} "
+                f"(time stamps around the call in the stamped replays)\n")
+    print(open(os.path.join(dst, "step_kernels.txt")).read())
+except Exception as e:      # noqa: BLE001
+    print("step_kernels.txt not written:", type(e).__name__, e)
+
 traffic = {"command": cmd, "rays_per_gpu": bench["config"]["rays_per_gpu"], "precision": bench["dtype"],
            "note": "means over the dispatches of one run; hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes)",
            "kernels": {}}

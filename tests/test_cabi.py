@@ -57,7 +57,7 @@ def test_argument_errors_without_gpu():
     lib.nerf_sort_rows.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     assert lib.nerf_sort_rows(1, 2000, ctypes.c_void_p(16), 0, None, ctypes.c_void_p(16), None) == -2
     lib.nerf_mlp_packed_bytes.restype = ctypes.c_int64
-    assert lib.nerf_mlp_packed_bytes() == (1216 + 1120) * 1024 + 13312 + 1184 * 1024 + (256 * 256 + 256 + 128 * 256) * 4
+    assert lib.nerf_mlp_packed_bytes() == (1216 + 1120) * 1024 + 13312 + 1184 * 1024 + (256 * 256 + 256 + 128 * 256) * 4 + 4096
     lib.nerf_mlp_saved_bytes.restype = ctypes.c_int64
     lib.nerf_mlp_saved_bytes.argtypes = [ctypes.c_int64]
     assert lib.nerf_mlp_saved_bytes(1) == 8 * (142 + 9) * 1024 and lib.nerf_mlp_saved_bytes(257) == 16 * (142 + 9) * 1024
@@ -91,6 +91,48 @@ def test_fp32_program_is_validated_on_the_host():
     assert run([layer(64, PTS, 100, A), layer(104, A, 3, RAW)]) == -4       # column 3 of raw stays unwritten
     assert run([layer(72, PTS, 100, A), layer(104, A, 4, RAW)]) == -4       # 63 encoded features pad to 64, not 72
     assert run([layer(64, PTS, 100, A), layer(104, A, 3, RAW, 2)]) == -4    # columns 2..4
+
+
+def test_fp32_backward_arguments_are_validated_on_the_host():
+    """nerf_mlp_fp32_bwd: sizes, the gradient descriptors and the workspace are checked before anything is launched"""
+    from nerf_amd import _C
+    lib = ctypes.CDLL(LIB)
+    lib.nerf_mlp_fp32_bwd.restype = ctypes.c_int
+    lib.nerf_mlp_fp32_bwd.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    for fn in (lib.nerf_mlp_fp32_saved_floats, lib.nerf_mlp_fp32_bwd_workspace_floats):
+        fn.restype = ctypes.c_int64
+        fn.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    FAKE = 0x10000
+    A, RAW, PTS = _C.FP32_BUF_A, _C.FP32_DST_RAW, _C.FP32_BUF_PTS
+    layers = (_C.Fp32Layer * 2)()
+    grads = (_C.Fp32Grad * 2)()
+    for L, (k, src, out, dst) in zip(layers, ((64, PTS, 100, A), (104, A, 4, RAW))):
+        L.n_segments = 1
+        L.weights[0], L.k_padded[0], L.src[0] = FAKE, k, src
+        L.bias, L.out_features, L.relu, L.dst, L.dst_col = FAKE, out, 1, dst, 0
+    for G, (ld, cols) in zip(grads, ((63, 63), (100, 100))):
+        G.d_weight, G.d_bias, G.ld = FAKE, FAKE, ld
+        G.col0[0], G.cols[0] = 0, cols
+    grads[1].wt[0] = FAKE
+    lp, gp = ctypes.cast(layers, ctypes.c_void_p), ctypes.cast(grads, ctypes.c_void_p)
+    rows = 64 + 0 + 100                                   # padded points, no views, one hidden layer
+    assert lib.nerf_mlp_fp32_saved_floats(130, 63, 0, lp, 2) == rows * 192      # 130 samples -> 3 tiles of 64
+    need = lib.nerf_mlp_fp32_bwd_workspace_floats(130, 63, 0, lp, 2)
+    assert need > (8 + 100) * 192
+    call = lambda M, ws, n: lib.nerf_mlp_fp32_bwd(M, 63, 0, lp, gp, 2, FAKE, FAKE, ws, n, None)   # noqa: E731
+    assert call(-1, FAKE, need) == -2
+    assert call(130, FAKE, need - 1) == -5                # workspace too small
+    assert call(130, None, need) == -1
+    assert call(130, FAKE + 4, need) == -3
+    grads[1].wt[0] = None                                 # a hidden source needs its transposed weights
+    assert call(130, FAKE, need) == -1
+    grads[1].wt[0] = FAKE
+    grads[0].cols[0] = 50                                 # does not round up to the layer's k_padded
+    assert call(130, FAKE, need) == -4
+    grads[0].cols[0] = 63
+    grads[1].ld = 90                                      # the segment's columns do not fit the row
+    assert call(130, FAKE, need) == -4
 
 
 def test_cpu_tensors_are_rejected():

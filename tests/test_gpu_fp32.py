@@ -1,6 +1,6 @@
-"""GPU parity of the fp32 validation mode (precision='fp32'): HIP encodings and compositing around
-fp32 library GEMMs.  Tolerances: raw 2e-5 abs (GEMM summation order only), maps 1e-3 abs on all rays,
-gradients 1e-3 relative."""
+"""GPU parity of the fp32 validation mode (precision='fp32'): HIP encodings and compositing around the fp32
+MFMA kernels (forward, backward-data chain, weight gradients).  Tolerances: raw 2e-5 abs (summation order only),
+maps 1e-3 abs on all rays, gradients 2e-3 relative against the reference and 2e-5 against library GEMMs."""
 import numpy as np
 import pytest
 import torch
@@ -110,10 +110,39 @@ def test_fp32_kernel_runs_every_architecture(amd, arch):
     cot = torch.randn(5, 7, 4, device=DEV)
     out = m(xp, xv) if xv is not None else m(xp)
     assert out.shape == (5, 7, 4)
+    ops.KERNEL_TIMES = {}
     g_kernel = torch.autograd.grad(out, list(m.parameters()), cot)
+    times, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+    assert "mlp_bwd_fp32" in times                     # the gradients are this library's kernels, not library GEMMs
     g_lib = torch.autograd.grad(m._forward_library(xp, xv, None), list(m.parameters()), cot)
     for a, b in zip(g_kernel, g_lib):
-        assert maxabs(a, b) <= 1e-6 * (1 + b.abs().max().item())
+        assert a.shape == b.shape and maxabs(a, b) <= 2e-5 * (1e-3 + b.abs().max().item())
+    # ragged sample counts (tiles of 64, chunks of the weight-gradient contraction), every parameter tensor:
+    # difference to the library's gradient relative to its norm.  fp32 products, summation order only: 2e-5 -- until,
+    # among millions of hidden units, a pre-activation lies within rounding of zero and its ReLU mask differs between
+    # the two evaluations (a flipped unit moves the gradients below it by its whole contribution): 2e-3 at 4097 samples
+    for M in (1, 200, 4097):
+        xp = torch.randn(M, m.input_ch_pts, device=DEV)
+        xv = torch.randn(M, m.input_ch_views, device=DEV) if m.use_viewdirs else None
+        cot = torch.randn(M, 4, device=DEV)
+        g_kernel = torch.autograd.grad(m(xp, xv) if xv is not None else m(xp), list(m.parameters()), cot)
+        g_lib = torch.autograd.grad(m._forward_library(xp, xv, None), list(m.parameters()), cot)
+        for (k, _), a, b in zip(m.named_parameters(), g_kernel, g_lib):
+            rel = ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+            assert rel < (2e-5 if M <= 200 else 5e-3), (arch, M, k, rel)
+    # size-independent: the gradient over 4097 samples is the sum of the gradients over two parts of them (a sample's
+    # masks do not depend on its batch), which checks tiles, chunks and tails without the mask-flip allowance
+    parts = [torch.autograd.grad(m(xp[a:b], xv[a:b]) if xv is not None else m(xp[a:b]), list(m.parameters()), cot[a:b])
+             for a, b in ((0, 2048), (2048, 4097))]
+    for (k, _), whole, p0, p1 in zip(m.named_parameters(), g_kernel, *parts):
+        rel = ((whole.double() - p0.double() - p1.double()).norm() / (whole.double().norm() + 1e-30)).item()
+        assert rel < 2e-6, (arch, k, rel)
+    # a gradient with respect to the encoded inputs still comes from the library path
+    xp = torch.randn(9, m.input_ch_pts, device=DEV, requires_grad=True)
+    xv = torch.randn(9, m.input_ch_views, device=DEV) if m.use_viewdirs else None
+    (m(xp, xv) if xv is not None else m(xp)).sum().backward()
+    assert xp.grad is not None and torch.isfinite(xp.grad).all() and xp.grad.abs().max() > 0
+    m.zero_grad()
     # weights changed in place under no_grad: the cached program follows
     with torch.no_grad():
         before = m(xp, xv) if xv is not None else m(xp)

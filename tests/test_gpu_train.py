@@ -268,13 +268,13 @@ def test_nan_weight_gives_non_finite_loss(amd, precision, where):
     assert not all(torch.isfinite(p.grad).all().item() for p in m.parameters())
 
 
-def test_adam_dev_clears_its_ticket(amd):
-    """nerf_adam_step_dev with garbage in the workgroup counter of its state (a caller that did not initialise it,
-    or a launch that aborted): the call clears the counter itself, the step count advances by one per call and
-    the update equals torch.optim.Adam's."""
+@pytest.mark.parametrize("n", [1, 1000, 70001, 600000])
+def test_adam_dev_counts_steps_and_leaves_its_ticket_clear(amd, n):
+    """nerf_adam_step_dev from a zero-initialised state, for one workgroup up to the grid's cap: the step count
+    advances by one per call, the workgroup counter in state[6] is 0 again after every call (the precondition of
+    the next one), and the update equals torch.optim.Adam's."""
     from nerf_amd import ops
     gen = torch.Generator().manual_seed(1)
-    n = 70001
     p0 = torch.randn(n, generator=gen)
     ref = p0.clone().requires_grad_(True)
     opt = torch.optim.Adam([ref], lr=5e-4)
@@ -282,7 +282,6 @@ def test_adam_dev_clears_its_ticket(amd):
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     state = torch.tensor([5e-4, 0.9, 0.999, 1e-8, 1.0, 0.0, 0.0, 0.0], device=DEV)
     for step in range(1, 5):
-        state.view(torch.int32)[6] = 12345 * step          # garbage ticket
         gr = torch.randn(n, generator=gen) * 0.1
         ref.grad = gr.clone()
         opt.step()
