@@ -211,7 +211,19 @@ def whole_frame_kernels(device):
         tf = 262144 * MLP_FWD_FLOP / r32["avg_us"] / 1e6
         out["mlp_fwd_fp32_262144_samples"] = {"avg_us": r32["avg_us"], "TFLOP/s": round(tf, 1), "peak_TFLOP/s": 157.3,
                                               "frac_of_fp32_mfma_peak": round(tf / 157.3, 4)}
-        del m32, xp, xv
+        # the same network's fp32 training pass: forward that keeps activations + backward-data chain + weight gradients
+        # (nerf_mlp_fp32_fwd_train, nerf_mlp_fp32_bwd), 3 489 024 FLOP per sample
+        cot = torch.randn(262144, 4, device=device)
+
+        def fwd_bwd():
+            with torch.enable_grad():
+                m32.zero_grad(set_to_none=True)
+                torch.autograd.backward([m32(xp, xv)], [cot])
+        r32b = rate(fwd_bwd, 0, iters=3)
+        tfb = 262144 * (MLP_FWD_FLOP + MLP_DGRAD_FLOP + MLP_WGRAD_FLOP) / r32b["avg_us"] / 1e6
+        out["mlp_fwd_bwd_fp32_262144_samples"] = {"avg_us": r32b["avg_us"], "TFLOP/s": round(tfb, 1), "peak_TFLOP/s": 157.3,
+                                                  "frac_of_fp32_mfma_peak": round(tfb / 157.3, 4)}
+        del m32, xp, xv, cot
         c2w = torch.eye(4, device=device)[:3].contiguous()
         out["get_rays_800x800"] = rate(lambda: ops.get_rays(800, 800, 1111.0, c2w), n * 24, iters=20)
         # 983 MB written per launch: four times the 256 MB infinity cache, so this is the HBM rate
@@ -418,6 +430,7 @@ def kernel_durations(mk, step_fn, kernel_steps, lr, sync, device):
         # the three large MLP calls only, one with stamps around everything else.
         big = ("mlp_fwd_train", "mlp_bwd_data", "mlp_bwd_weights")
         rate = None
+        replay_ms = {}
         for names in (big, None):
             stamper = Stamper(device, names=names)
             rate = stamper.rate
@@ -438,8 +451,12 @@ def kernel_durations(mk, step_fn, kernel_steps, lr, sync, device):
                 raise RuntimeError("no call of the step was stamped")
             st2(st2.rays_o, st2.rays_d, st2.target, lr=lr)
             for _ in range(kernel_steps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 st2(st2.rays_o, st2.rays_d, st2.target, lr=lr)
+                e1.record()
                 sync()
+                replay_ms.setdefault("large calls stamped" if names is big else "other calls stamped", []).append(e0.elapsed_time(e1))
                 t = stamper.slots.cpu()
                 own = float(t[stamper.pair[1]] - t[stamper.pair[0]])
                 for name, lst in pairs.items():
@@ -450,7 +467,8 @@ def kernel_durations(mk, step_fn, kernel_steps, lr, sync, device):
         timing = ("one-lane time-stamp kernels (the device's %.0f MHz counter) captured into copies of the step's graph in "
                   "front of and behind each C-ABI call, on the stream the kernels are launched on, less the distance of two "
                   "back-to-back stamps; %d replays right after the timed region (one copy stamps the three large MLP calls, "
-                  "another the rest)" % (rate / 1e6, kernel_steps))
+                  "another the rest); a replay of the stamped copies took %s ms"
+                  % (rate / 1e6, kernel_steps, ", ".join("%s: %.4f" % (k, sorted(v)[len(v) // 2]) for k, v in replay_ms.items())))
     else:
         step_fn(step_fn.rays_o, step_fn.rays_d, step_fn.target, lr=lr)
         ops.KERNEL_TIMES = {}

@@ -240,6 +240,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_dgrad_kernel(const BwdAr
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef NERF_PRIO_UPPER        // experiment: static priority for the later-dispatched half of the workgroup
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int c = lane & 31, h = lane >> 5;
 #ifdef NERF_ABL_LANE_LINEAR      // timing experiment only (wrong layout): lanes store in address order
     const int lane_off = lane * 16;
@@ -704,6 +707,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
 template <int PREC>
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[WG_LDS_BYTES];
+#ifdef NERF_PRIO_UPPER
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef NERF_WG_STAMP
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif

@@ -173,6 +173,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd_kernel(const FwdArgs
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef NERF_PRIO_UPPER        // experiment: static priority for the later-dispatched half of the workgroup
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int c = lane & 31, h = lane >> 5;
 #ifdef NERF_ABL_LANE_LINEAR      // timing experiment only (wrong layout): lanes store in address order
     const int lane_off = lane * 16;

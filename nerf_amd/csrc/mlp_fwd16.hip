@@ -116,6 +116,9 @@ __global__ __launch_bounds__(CHAIN_THREADS, 2) void mlp_fwd16_kernel(const Fwd16
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef NERF_PRIO_UPPER        // experiment: static priority for the later-dispatched half of the workgroup
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int n = lane & 15, g = lane >> 4;
 
     load_bias_table<VIEW>(bias_lds, a.packed);       // (and the check for non-finite parameters)
