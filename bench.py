@@ -223,7 +223,34 @@ def whole_frame_kernels(device):
         tfb = 262144 * (MLP_FWD_FLOP + MLP_DGRAD_FLOP + MLP_WGRAD_FLOP) / r32b["avg_us"] / 1e6
         out["mlp_fwd_bwd_fp32_262144_samples"] = {"avg_us": r32b["avg_us"], "TFLOP/s": round(tfb, 1), "peak_TFLOP/s": 157.3,
                                                   "frac_of_fp32_mfma_peak": round(tfb / 157.3, 4)}
-        del m32, xp, xv, cot
+        del m32
+        # the 16-bit layer-program kernels (any architecture) on the same network and inputs, run through the program
+        # path on purpose (the scripts' network itself goes to the fused chain kernels): durations between HIP events
+        # around the C calls, without the Python-side weight packing
+        from nerf_amd.models.nerf import _ProgramForward
+        mp = seed_parameters_(NeRF(precision="bf16").to(device), 0)
+        ops.KERNEL_TIMES = {}
+        try:
+            for _ in range(4):
+                with torch.no_grad():
+                    _ProgramForward.apply(mp, xp, xv, False, "bf16", *mp.ordered_params())
+                with torch.enable_grad():
+                    mp.zero_grad(set_to_none=True)
+                    torch.autograd.backward([_ProgramForward.apply(mp, xp, xv, True, "bf16", *mp.ordered_params())], [cot])
+            torch.cuda.synchronize()
+            evs, ops.KERNEL_TIMES = ops.KERNEL_TIMES, None
+        finally:
+            ops.KERNEL_TIMES = None
+        us = {k: sum(a.elapsed_time(b) * 1e3 for a, b, _ in v[1:]) / (len(v) - 1) for k, v in evs.items()}
+        tfp = 262144 * MLP_FWD_FLOP / us["mlp_fwd_p16"] / 1e6
+        out["mlp_fwd_p16_bf16_262144_samples"] = {"avg_us": round(us["mlp_fwd_p16"], 1), "TFLOP/s": round(tfp, 1),
+                                                  "frac_of_mfma_peak": round(tfp / MFMA_PEAK_TFLOPS, 4)}
+        tb = us["mlp_fwd_p16_train"] + us["mlp_bwd_p16"]
+        tfpb = 262144 * (MLP_FWD_FLOP + MLP_DGRAD_FLOP + MLP_WGRAD_FLOP) / tb / 1e6
+        out["mlp_fwd_bwd_p16_bf16_262144_samples"] = {"avg_us": round(tb, 1), "fwd_train_us": round(us["mlp_fwd_p16_train"], 1),
+                                                      "bwd_us": round(us["mlp_bwd_p16"], 1), "TFLOP/s": round(tfpb, 1),
+                                                      "frac_of_mfma_peak": round(tfpb / MFMA_PEAK_TFLOPS, 4)}
+        del mp, xp, xv, cot
         c2w = torch.eye(4, device=device)[:3].contiguous()
         out["get_rays_800x800"] = rate(lambda: ops.get_rays(800, 800, 1111.0, c2w), n * 24, iters=20)
         # 983 MB written per launch: four times the 256 MB infinity cache, so this is the HBM rate

@@ -279,6 +279,33 @@ int nerf_mlp_fp32_bwd(int64_t M, int cp, int cv, const nerf_fp32_layer_t *layers
                       int n_layers, const float *d_raw, const float *saved, float *workspace,
                       int64_t workspace_floats, void *stream);
 
+/* ------------------------------------------------------------------------
+ * The same layer programs with 16-bit operands (NERF_PREC_BF16 / NERF_PREC_FP16, fp32 accumulation, fp32 bias and
+ * raw) on v_mfma_f32_32x32x16: NeRF.forward and its parameter gradients (src/nerf_project/models/nerf.py:173-209,
+ * scripts/train_nerf.py:334-335) for the architectures the constructor (:100-153) accepts that the unrolled 16-bit
+ * kernels above (nerf_mlp_fwd / nerf_mlp_bwd_*) are not compiled for, e.g. the reference's own test network D=4,
+ * W=64, skips=[2] (tests/test_nerf_model.py:105-109).  Same arithmetic model as those kernels: weights and every
+ * layer's input rounded to the operand type.  The entry points mirror the nerf_mlp_fp32_* ones and take the same
+ * nerf_fp32_layer_t / nerf_fp32_grad_t lists, with these differences: a segment's input features are padded to a
+ * multiple of 16 (k_padded, and the cols of a gradient segment rounded up to 16); `weights` and `wt` point to
+ * nerf_mlp_p16_pack_segment outputs (16-bit, cast to the struct's pointer type); saved activations and the gradient
+ * rows are kept in the operand type (sizes in bytes; saved 16-byte, workspace 256-byte aligned); grad_scale
+ * (nullable, device): d_raw is multiplied by *grad_scale on entry and the gradients divided by it on exit, which
+ * keeps fp16 gradients inside the format's range (a power of two keeps the result unchanged otherwise).
+ */
+int64_t nerf_mlp_p16_segment_bytes(int rows, int cols);
+int nerf_mlp_p16_pack_segment(const float *w, int rows, int ld, int col0, int cols, int precision, void *dst, void *stream);
+int nerf_mlp_p16_fwd(int64_t M, const float *x_pts, int cp, const float *x_views, int cv,
+                     const nerf_fp32_layer_t *layers, int n_layers, int precision, float *raw, void *stream);
+int64_t nerf_mlp_p16_saved_bytes(int64_t M, int cp, int cv, const nerf_fp32_layer_t *layers, int n_layers);
+int64_t nerf_mlp_p16_bwd_workspace_bytes(int64_t M, int cp, int cv, const nerf_fp32_layer_t *layers, int n_layers);
+int nerf_mlp_p16_fwd_train(int64_t M, const float *x_pts, int cp, const float *x_views, int cv,
+                           const nerf_fp32_layer_t *layers, int n_layers, int precision, float *raw, void *saved,
+                           void *stream);
+int nerf_mlp_p16_bwd(int64_t M, int cp, int cv, const nerf_fp32_layer_t *layers, const nerf_fp32_grad_t *grads,
+                     int n_layers, int precision, const float *d_raw, const void *saved, const float *grad_scale,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+
 /* The same forward as nerf_mlp_fwd_encoded(saved = NULL) with the workspace inside the library.  It has no
  * counterpart in the reference: it exists for callers that cannot allocate device memory -- code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The call allocates nothing

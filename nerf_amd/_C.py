@@ -58,6 +58,13 @@ _SIGS = {
     "nerf_mlp_fp32_bwd_workspace_floats": (c_int64, [c_int64, c_int, c_int, P, c_int]),
     "nerf_mlp_fp32_fwd_train": (c_int, [c_int64, P, c_int, P, c_int, P, c_int, P, P, P]),
     "nerf_mlp_fp32_bwd": (c_int, [c_int64, c_int, c_int, P, P, c_int, P, P, P, c_int64, P]),
+    "nerf_mlp_p16_segment_bytes": (c_int64, [c_int, c_int]),
+    "nerf_mlp_p16_pack_segment": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "nerf_mlp_p16_fwd": (c_int, [c_int64, P, c_int, P, c_int, P, c_int, c_int, P, P]),
+    "nerf_mlp_p16_saved_bytes": (c_int64, [c_int64, c_int, c_int, P, c_int]),
+    "nerf_mlp_p16_bwd_workspace_bytes": (c_int64, [c_int64, c_int, c_int, P, c_int]),
+    "nerf_mlp_p16_fwd_train": (c_int, [c_int64, P, c_int, P, c_int, P, c_int, c_int, P, P, P]),
+    "nerf_mlp_p16_bwd": (c_int, [c_int64, c_int, c_int, P, P, c_int, c_int, P, P, P, P, c_int64, P]),
     "nerf_adam_step_dev": (c_int, [c_int64, P, P, P, P, P, P]),
     "nerf_mse_pair": (c_int, [c_int64, P, P, P, P, P, P, P]),
     "nerf_adam_step": (c_int, [c_int64, P, P, P, P, c_float, c_float, c_float, c_float, c_int64, c_float, P]),

@@ -86,9 +86,8 @@ def build_models(ckpt: Mapping[str, Any], device="cuda", precision: str = "bf16"
     kw = dict(D=int(cfg["net_depth"]), W=int(cfg["net_width"]), input_ch_pts=pe.output_dims,
               input_ch_views=pv.output_dims if pv is not None else 0, skips=[int(cfg["net_depth"]) // 2],
               use_viewdirs=bool(cfg["use_viewdirs"]))
-    probe = NeRF(precision=precision, **kw)
-    if precision != "fp32" and not probe.kernel_supported():
-        precision = "fp32"                    # architectures outside the fused kernels run in validation mode
+    # (an architecture outside the fused kernels keeps the requested operand type: it runs on the layer-program
+    # kernels; NeRF.effective_precision() says what a network beyond those runs in)
     mc = NeRF(precision=precision, **kw)
     mc.load_state_dict(ckpt["model_coarse_state_dict"])
     mc = mc.to(device).eval()
@@ -97,5 +96,5 @@ def build_models(ckpt: Mapping[str, Any], device="cuda", precision: str = "bf16"
         mf = NeRF(precision=precision, **kw)
         mf.load_state_dict(ckpt["model_fine_state_dict"])
         mf = mf.to(device).eval()
-    cfg["precision"] = precision
+    cfg["precision"] = mc.effective_precision()
     return mc, mf, pe, pv, cfg

@@ -15,7 +15,9 @@
 // written by nerf_mlp_fp32_pack_segment: one coalesced 1 KiB read per tile and chunk.  A layer's input
 // is one or two segments (skip connection: [encoded points, hidden]; colour head: [feature, encoded
 // view direction]), its output goes to the other LDS buffer or straight to columns of raw [M,4].
+#include <type_traits>
 #include "common.hpp"
+#include "mlp_prog.hpp"
 
 namespace nerf {
 namespace fp32 {
@@ -34,20 +36,8 @@ constexpr int OFF_RED = OFF_HB + BUF_FLOATS_H;      // partial sums of the outpu
 constexpr int LDS_FLOATS = OFF_RED + WAVES * TILE * 4;   // 160 KiB
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 
-// Optional per-layer side channels in global memory, all "transposed": one row of ldm floats per feature,
-// samples along the row (ldm = M rounded up to whole tiles), so that a wave's 32 samples of one feature are one
-// 128-byte run.  The training forward keeps every hidden layer's output and the encoded inputs there; the
-// backward-data chain -- the same kernel run on the transposed weights -- gates its outputs with them
-// (relu'(y) = [y > 0]) and keeps every layer's gradient for the weight-gradient pass.
-struct Program {
-    nerf_fp32_layer_t layer[NERF_FP32_MAX_LAYERS];
-    float* save[NERF_FP32_MAX_LAYERS];         // nullable: rows = the layer's output features (after the epilogue)
-    const float* gate[NERF_FP32_MAX_LAYERS];   // nullable: outputs are zeroed where this tensor is <= 0
-    float* save_pts;                           // nullable: the padded input rows as loaded (cp_pad rows)
-    float* save_views;                         // nullable (cv_pad rows)
-    int64_t ldm;
-    int n_layers;
-};
+constexpr int KPAD = 8;                 // input features per weight chunk
+typedef prog::Program<float> Program;     // layer list + the transposed side channels (mlp_prog.hpp)
 
 // max(x, 0) that keeps a NaN a NaN, as torch.relu does (fmaxf would return 0: a diverged network must stay visible)
 __device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.0f ? 0.0f : x; }
@@ -201,24 +191,35 @@ __global__ __launch_bounds__(THREADS) void mlp_fp32_kernel(int64_t M, const floa
                 f32x16 acc0 = head.bias, acc1 = head.bias;
                 const int seg_off[2] = {buf_off(L.src[0]), buf_off(L.src[L.n_segments > 1 ? 1 : 0])};
                 const int first = split ? 32 * (wave / (WAVES / 2)) : 0;
+                const float* gate = prog.gate[li];
+                float* save = prog.save[li];
+                // register r of lane (n, h) is feature 32 ft + 8 (r >> 2) + 4 h + (r & 3) of sample first + n (+ 32).  The
+                // gate values are requested before the k loop: they arrive behind its MFMAs, not in front of the epilogue
+                float g0[16], g1[16];
+                if (gate != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = 32 * ft + 8 * (r >> 2) + 4 * h + (r & 3);
+                        const int64_t at = (int64_t)(f < L.out_features ? f : 0) * prog.ldm + m0 + first + n;
+                        g0[r] = gate[at];
+                        g1[r] = split ? 1.0f : gate[at + 32];
+                    }
+                }
                 if (split) tile_chunks<1>(L, lds, seg_off, ft, first, lane, head, acc0, acc1);
                 else tile_chunks<2>(L, lds, seg_off, ft, 0, lane, head, acc0, acc1);
                 if (L.relu) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { acc0[r] = relu_keep_nan(acc0[r]); acc1[r] = relu_keep_nan(acc1[r]); }
                 }
-                const float* gate = prog.gate[li];
-                float* save = prog.save[li];
                 if (gate != nullptr || save != nullptr) {
-                    // register r of lane (n, h) is feature 32 ft + 8 (r >> 2) + 4 h + (r & 3) of sample first + n (+ 32)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int f = 32 * ft + 8 * (r >> 2) + 4 * h + (r & 3);
                         if (f < L.out_features) {
                             const int64_t at = (int64_t)f * prog.ldm + m0 + first + n;
                             if (gate != nullptr) {
-                                if (!(gate[at] > 0.0f)) acc0[r] = 0.0f;
-                                if (!split && !(gate[at + 32] > 0.0f)) acc1[r] = 0.0f;
+                                if (!(g0[r] > 0.0f)) acc0[r] = 0.0f;
+                                if (!split && !(g1[r] > 0.0f)) acc1[r] = 0.0f;
                             }
                             if (save != nullptr) {
                                 save[at] = acc0[r];
@@ -281,7 +282,9 @@ __global__ __launch_bounds__(256) void fp32_wgrad_kernel(const WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kk = lane >> 5;
-    const int ot = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
+    // chunk on the fast grid axis: workgroups are dealt to the eight XCDs round robin, so with a chunk count that is a
+    // multiple of eight the row tiles of one chunk -- which all read the same input rows -- share one XCD's L2
+    const int chunk = blockIdx.x, ot = blockIdx.y, n_chunks = gridDim.x;
     const int n_it = a.in_pad >> 5;
     const int64_t per = (a.steps + n_chunks - 1) / n_chunks;
     const int64_t st0 = chunk * per, st1 = st0 + per < a.steps ? st0 + per : a.steps;
@@ -303,27 +306,44 @@ __global__ __launch_bounds__(256) void fp32_wgrad_kernel(const WgradArgs a) {
         pB[t] = reinterpret_cast<const f32x4*>(a.Bt + (int64_t)(validB[t] ? rowB : 0) * a.ldm + 16 * kk);
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t st = st0; st < st1; ++st) {
+    // U steps per iteration, all their loads issued before the first MFMA (a step alone keeps too few bytes in flight
+    // to cover the memory latency)
+    auto steps = [&](auto UC, int64_t st) {
+        constexpr int U = decltype(UC)::value;
         const int64_t m4 = st * 8;            // 32 samples = 8 float4
-        f32x4 av[4];
+        f32x4 av[U][4], bv[WG_MAX_COL_TILES][U][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) av[e] = validA ? pA[m4 + e] : zero4;
-        if (wave == 0) {
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bsum += (av[e][0] + av[e][1]) + (av[e][2] + av[e][3]);
-        }
+            for (int e = 0; e < 4; ++e) av[u][e] = validA ? pA[m4 + 8 * u + e] : zero4;
 #pragma unroll
         for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
             if (wave + 4 * t >= n_it) continue;          // wave-uniform
-            f32x4 bv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = validB[t] ? pB[t][m4 + e] : zero4;
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e][j], bv[e][j], acc[t], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) bv[t][u][e] = validB[t] ? pB[t][m4 + 8 * u + e] : zero4;
         }
-    }
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum += (av[u][e][0] + av[u][e][1]) + (av[u][e][2] + av[u][e][3]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
+                if (wave + 4 * t >= n_it) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e][j], bv[t][u][e][j], acc[t], 0, 0, 0);
+            }
+    };
+    int64_t st = st0;
+    for (; st + 2 <= st1; st += 2) steps(std::integral_constant<int, 2>(), st);
+    for (; st < st1; ++st) steps(std::integral_constant<int, 1>(), st);
     // accumulator register r of lane (n = lane & 31, h = lane >> 5): row 8 (r >> 2) + 4 h + (r & 3), column n
     float* part = a.part + (int64_t)chunk * a.out_pad * a.in_pad;
 #pragma unroll
@@ -341,32 +361,11 @@ __global__ __launch_bounds__(256) void fp32_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-struct WgradReduceArgs {
-    const float* part; const float* part_bias;
-    int n_chunks, out, in, out_pad, in_pad;
-    float* d_weight; int ld, col0;     // d_weight[row * ld + col0 + col]
-    float* d_bias;                     // nullable
-};
-__global__ __launch_bounds__(256) void fp32_wgrad_reduce_kernel(const WgradReduceArgs a) {
-    const int64_t total = (int64_t)a.out * a.in;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        const int row = (int)(i / a.in), col = (int)(i - (int64_t)row * a.in);
-        float v = 0.0f;
-        for (int c = 0; c < a.n_chunks; ++c) v += a.part[((int64_t)c * a.out_pad + row) * a.in_pad + col];
-        a.d_weight[(int64_t)row * a.ld + a.col0 + col] = v;
-    } else if (a.d_bias != nullptr && i < total + a.out) {
-        const int row = (int)(i - total);
-        float v = 0.0f;
-        for (int c = 0; c < a.n_chunks; ++c) v += a.part_bias[(int64_t)c * a.out_pad + row];
-        a.d_bias[row] = v;
-    }
-}
-
 }  // namespace fp32
 }  // namespace nerf
 
 using namespace nerf::fp32;
+namespace prog = nerf::prog;
 
 extern "C" int64_t nerf_mlp_fp32_segment_floats(int rows, int cols) {
     if (rows <= 0 || cols <= 0) return 0;
@@ -385,99 +384,24 @@ extern "C" int nerf_mlp_fp32_pack_segment(const float* w, int rows, int ld, int 
     return nerf_launch_status();
 }
 
-// Checks a layer list and copies it into a kernel program.  On success `prod[l][s]` names the layer whose output
-// segment s of layer l reads (-1: encoded points, -2: encoded view directions).
-static int build_program(int cp, int cv, bool have_views, const nerf_fp32_layer_t* layers, int n_layers, Program* prog,
-                         int (*prod)[2]) {
-    NERF_REQUIRE(layers, NERF_E_NULL);
-    NERF_REQUIRE(n_layers >= 1 && n_layers <= NERF_FP32_MAX_LAYERS, NERF_E_ARCH);
-    NERF_REQUIRE(cp >= 1 && cp <= MAX_CP && cv >= 0 && cv <= MAX_CV && (have_views || cv == 0), NERF_E_ARCH);
-    *prog = Program{};
-    prog->n_layers = n_layers;
-    // Every index a layer names is checked here: the kernel trusts the program.  `width[b]` is how many
-    // features of buffer b hold defined values: the padded input widths, and for a hidden buffer the rows its
-    // last writer produced (whole 32-row tiles: rows past out_features come out as zeros).  A layer may not
-    // read beyond that, or it would multiply its zero-padded weights with stale LDS contents.
-    int written = (1 << NERF_FP32_BUF_PTS) | (have_views ? 1 << NERF_FP32_BUF_VIEWS : 0);
-    int width[4] = {(cp + 7) & ~7, (cv + 7) & ~7, 0, 0};
-    int live[4] = {-1, -2, -3, -3};
-    int raw_cols = 0;
-    for (int i = 0; i < n_layers; ++i) {
-        const nerf_fp32_layer_t& L = layers[i];
-        NERF_REQUIRE(L.n_segments >= 1 && L.n_segments <= 2 && L.bias, NERF_E_ARCH);
-        NERF_REQUIRE(L.out_features >= 1, NERF_E_ARCH);
-        for (int s = 0; s < L.n_segments; ++s) {
-            NERF_REQUIRE(L.weights[s], NERF_E_NULL);
-            NERF_REQUIRE(nerf_aligned(L.weights[s], 16), NERF_E_ALIGN);
-            NERF_REQUIRE(L.src[s] >= NERF_FP32_BUF_PTS && L.src[s] <= NERF_FP32_BUF_B && ((written >> L.src[s]) & 1), NERF_E_ARCH);
-            NERF_REQUIRE(L.k_padded[s] >= 8 && L.k_padded[s] % 8 == 0 && L.k_padded[s] <= width[L.src[s]], NERF_E_ARCH);
-            NERF_REQUIRE(L.src[s] != L.dst, NERF_E_ARCH);
-            if (prod) prod[i][s] = live[L.src[s]];
-        }
-        if (L.dst == NERF_FP32_DST_RAW) {
-            NERF_REQUIRE(L.dst_col >= 0 && L.dst_col + L.out_features <= 4, NERF_E_ARCH);
-            raw_cols |= ((1 << L.out_features) - 1) << L.dst_col;
-        } else {
-            NERF_REQUIRE(L.dst == NERF_FP32_BUF_A || L.dst == NERF_FP32_BUF_B, NERF_E_ARCH);
-            NERF_REQUIRE(L.out_features <= MAX_W, NERF_E_ARCH);
-            written |= 1 << L.dst;
-            width[L.dst] = (L.out_features + 31) / 32 * 32;
-            live[L.dst] = i;
-        }
-        prog->layer[i] = L;
-    }
-    NERF_REQUIRE(raw_cols == 0xf, NERF_E_ARCH);      // the program must write all four columns of raw
-    return NERF_OK;
-}
-
 static inline int64_t fp32_ldm(int64_t M) { return (M + TILE - 1) / TILE * TILE; }
 static inline unsigned fp32_grid(int64_t M) {
     const int64_t n_tiles = (M + TILE - 1) / TILE;
     return (unsigned)(n_tiles < 256 ? n_tiles : 256);
 }
 
-// rows of the saved buffer: encoded points (padded), encoded view directions (padded), then each hidden layer's output
-static int64_t saved_rows(int cp, int cv, const nerf_fp32_layer_t* layers, int n_layers, int64_t* row_of_layer) {
-    int64_t rows = ((cp + 7) & ~7) + ((cv + 7) & ~7);
-    for (int i = 0; i < n_layers; ++i) {
-        if (row_of_layer) row_of_layer[i] = rows;
-        if (layers[i].dst != NERF_FP32_DST_RAW) rows += layers[i].out_features;
-    }
-    return rows;
-}
-
 extern "C" int64_t nerf_mlp_fp32_saved_floats(int64_t M, int cp, int cv, const nerf_fp32_layer_t* layers, int n_layers) {
     if (M < 0 || !layers || n_layers < 1 || n_layers > NERF_FP32_MAX_LAYERS) return -1;
-    return saved_rows(cp, cv, layers, n_layers, nullptr) * fp32_ldm(M);
-}
-
-// chunks of the sample axis of one weight-gradient launch: enough workgroups to fill the chip, at least four steps each
-static int wgrad_chunks(int64_t steps, int out_tiles) {
-    int64_t c = (512 + out_tiles - 1) / out_tiles;
-    if (c > steps / 4) c = steps / 4;
-    if (c > 64) c = 64;
-    return c < 1 ? 1 : (int)c;
+    return prog::saved_rows<KPAD>(cp, cv, layers, n_layers, nullptr) * fp32_ldm(M);
 }
 
 // workspace of nerf_mlp_fp32_bwd: the gradient rows (8 for d_raw, then every hidden layer's output gradient),
 // then the partial blocks of the largest weight-gradient launch
 static int64_t bwd_workspace(int64_t M, const nerf_fp32_layer_t* layers, int n_layers, int64_t* part_off) {
     const int64_t ldm = fp32_ldm(M);
-    int64_t rows = 8;
-    int64_t part = 0;
-    for (int i = 0; i < n_layers; ++i) {
-        const nerf_fp32_layer_t& L = layers[i];
-        if (L.dst != NERF_FP32_DST_RAW) rows += L.out_features;
-        const int out_pad = (L.out_features + 31) / 32 * 32;
-        for (int s = 0; s < L.n_segments; ++s) {
-            const int in_pad = (L.k_padded[s] + 31) / 32 * 32;
-            const int64_t need = (int64_t)wgrad_chunks(ldm / 32, out_pad / 32) * out_pad * (in_pad + 1);
-            if (need > part) part = need;
-        }
-    }
-    const int64_t off = (rows * ldm + 63) / 64 * 64;
+    const int64_t off = (prog::grad_rows<KPAD>(layers, n_layers, nullptr) * ldm + 63) / 64 * 64;
     if (part_off) *part_off = off;
-    return off + part;
+    return off + prog::partial_floats<KPAD>(ldm, layers, n_layers);
 }
 
 extern "C" int64_t nerf_mlp_fp32_bwd_workspace_floats(int64_t M, int cp, int cv, const nerf_fp32_layer_t* layers, int n_layers) {
@@ -491,20 +415,20 @@ static int fp32_forward(int64_t M, const float* x_pts, int cp, const float* x_vi
     NERF_REQUIRE(M >= 0, NERF_E_SHAPE);
     if (M == 0) return NERF_OK;
     NERF_REQUIRE(x_pts && layers && raw, NERF_E_NULL);
-    Program prog;
-    const int rc = build_program(cp, cv, x_views != nullptr, layers, n_layers, &prog, nullptr);
+    Program fwd;
+    const int rc = prog::build_program<float, KPAD>(cp, cv, x_views != nullptr, layers, n_layers, &fwd, nullptr);
     if (rc) return rc;
-    prog.ldm = fp32_ldm(M);
+    fwd.ldm = fp32_ldm(M);
     if (saved != nullptr) {
         NERF_REQUIRE(nerf_aligned(saved, 16), NERF_E_ALIGN);
         int64_t row[NERF_FP32_MAX_LAYERS];
-        saved_rows(cp, cv, layers, n_layers, row);
-        prog.save_pts = saved;
-        prog.save_views = x_views ? saved + (int64_t)((cp + 7) & ~7) * prog.ldm : nullptr;
+        prog::saved_rows<KPAD>(cp, cv, layers, n_layers, row);
+        fwd.save_pts = saved;
+        fwd.save_views = x_views ? saved + (int64_t)prog::pad_k<KPAD>(cp) * fwd.ldm : nullptr;
         for (int i = 0; i < n_layers; ++i)
-            if (layers[i].dst != NERF_FP32_DST_RAW) prog.save[i] = saved + row[i] * prog.ldm;
+            if (layers[i].dst != NERF_FP32_DST_RAW) fwd.save[i] = saved + row[i] * fwd.ldm;
     }
-    hipLaunchKernelGGL(mlp_fp32_kernel, dim3(fp32_grid(M)), dim3(THREADS), 0, (hipStream_t)stream, M, x_pts, cp, x_views, cv, prog, raw);
+    hipLaunchKernelGGL(mlp_fp32_kernel, dim3(fp32_grid(M)), dim3(THREADS), 0, (hipStream_t)stream, M, x_pts, cp, x_views, cv, fwd, raw);
     return nerf_launch_status();
 }
 
@@ -526,21 +450,10 @@ extern "C" int nerf_mlp_fp32_bwd(int64_t M, int cp, int cv, const nerf_fp32_laye
     NERF_REQUIRE(layers && grads, NERF_E_NULL);
     Program fwd;
     int prod[NERF_FP32_MAX_LAYERS][2];
-    int rc = build_program(cp, cv, cv > 0, layers, n_layers, &fwd, prod);
+    int rc = prog::build_program<float, KPAD>(cp, cv, cv > 0, layers, n_layers, &fwd, prod);
     if (rc) return rc;
-    for (int c = 0; c < n_layers; ++c) {
-        const nerf_fp32_layer_t& L = layers[c];
-        const nerf_fp32_grad_t& G = grads[c];
-        NERF_REQUIRE(G.d_weight && G.d_bias, NERF_E_NULL);
-        int total = 0;
-        for (int s = 0; s < L.n_segments; ++s) {
-            NERF_REQUIRE(G.cols[s] >= 1 && ((G.cols[s] + 7) & ~7) == L.k_padded[s] && G.col0[s] >= 0, NERF_E_ARCH);
-            NERF_REQUIRE(G.col0[s] + G.cols[s] <= G.ld, NERF_E_ARCH);
-            NERF_REQUIRE(prod[c][s] < 0 || (G.wt[s] != nullptr && nerf_aligned(G.wt[s], 16)), NERF_E_NULL);
-            total += G.cols[s];
-        }
-        NERF_REQUIRE(total <= G.ld, NERF_E_ARCH);
-    }
+    rc = prog::check_grads<KPAD>(layers, grads, n_layers, prod);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) {       // no samples: zero gradients
         for (int c = 0; c < n_layers; ++c) {
@@ -555,54 +468,19 @@ extern "C" int nerf_mlp_fp32_bwd(int64_t M, int cp, int cv, const nerf_fp32_laye
     int64_t part_off = 0;
     NERF_REQUIRE(workspace_floats >= bwd_workspace(M, layers, n_layers, &part_off), NERF_E_WORKSPACE);
     const int64_t ldm = fp32_ldm(M);
-    const int cp_pad = (cp + 7) & ~7;
-    int64_t yrow[NERF_FP32_MAX_LAYERS];
-    saved_rows(cp, cv, layers, n_layers, yrow);
-    // gradient rows in the workspace: d_raw transposed (8 rows, written by the chain's input load), then dZ of every hidden layer
-    int64_t zrow[NERF_FP32_MAX_LAYERS];
-    {
-        int64_t r = 8;
-        for (int c = 0; c < n_layers; ++c) {
-            if (layers[c].dst == NERF_FP32_DST_RAW) zrow[c] = layers[c].dst_col;
-            else { zrow[c] = r; r += layers[c].out_features; }
-        }
-    }
+    const int cp_pad = prog::pad_k<KPAD>(cp);
+    int64_t yrow[NERF_FP32_MAX_LAYERS], zrow[NERF_FP32_MAX_LAYERS];
+    prog::saved_rows<KPAD>(cp, cv, layers, n_layers, yrow);
+    prog::grad_rows<KPAD>(layers, n_layers, zrow);
     // ---- 1. backward-data chain: the forward kernel on the transposed weights, hidden tensors in reverse order ----
-    // The gradient of a hidden layer p's output lives in the LDS buffer its output lived in.  It is the sum over the
-    // layers c that read that output of W_c[:, segment]^T dZ_c, where dZ_c is in c's own buffer -- or, for an output
-    // layer, in the input buffer that holds d_raw -- gated by [y_p > 0] when p has a ReLU.
-    Program chain{};
-    chain.ldm = ldm;
-    chain.save_pts = workspace;
-    int n_chain = 0;
-    for (int p = n_layers - 1; p >= 0; --p) {
-        const nerf_fp32_layer_t& P = layers[p];
-        if (P.dst == NERF_FP32_DST_RAW) continue;
-        nerf_fp32_layer_t C{};
-        for (int c = p + 1; c < n_layers; ++c)
-            for (int s = 0; s < layers[c].n_segments; ++s) {
-                if (prod[c][s] != p) continue;
-                NERF_REQUIRE(C.n_segments < 2, NERF_E_ARCH);       // at most two readers of one hidden tensor
-                const bool out_layer = layers[c].dst == NERF_FP32_DST_RAW;
-                C.weights[C.n_segments] = grads[c].wt[s];
-                C.k_padded[C.n_segments] = out_layer ? 8 : (layers[c].out_features + 7) & ~7;
-                C.src[C.n_segments] = out_layer ? NERF_FP32_BUF_PTS : layers[c].dst;
-                ++C.n_segments;
-            }
-        float* dz = workspace + zrow[p] * ldm;
-        if (C.n_segments == 0) {       // nobody reads this layer: its gradient is zero
-            const hipError_t e = hipMemsetAsync(dz, 0, sizeof(float) * P.out_features * ldm, st);
-            if (e != hipSuccess) return (int)e;
-            continue;
-        }
-        NERF_REQUIRE(n_chain < NERF_FP32_MAX_LAYERS, NERF_E_ARCH);
-        C.bias = nullptr; C.out_features = P.out_features; C.relu = 0; C.dst = P.dst; C.dst_col = 0;
-        chain.layer[n_chain] = C;
-        chain.gate[n_chain] = P.relu ? saved + yrow[p] * ldm : nullptr;
-        chain.save[n_chain] = dz;
-        ++n_chain;
+    Program chain;
+    int dead[NERF_FP32_MAX_LAYERS], n_dead = 0;
+    rc = prog::build_chain<float, KPAD>(layers, grads, n_layers, prod, saved, workspace, yrow, zrow, ldm, &chain, dead, &n_dead);
+    if (rc) return rc;
+    for (int i = 0; i < n_dead; ++i) {       // nobody reads this layer: its gradient is zero
+        const hipError_t e = hipMemsetAsync(workspace + zrow[dead[i]] * ldm, 0, sizeof(float) * layers[dead[i]].out_features * ldm, st);
+        if (e != hipSuccess) return (int)e;
     }
-    chain.n_layers = n_chain;
     // (with no hidden layer at all the kernel still runs its input load, which writes d_raw transposed)
     hipLaunchKernelGGL(mlp_fp32_kernel, dim3(fp32_grid(M)), dim3(THREADS), 0, st, M, d_raw, 4, (const float*)nullptr, 0, chain,
                        (float*)nullptr);
@@ -621,19 +499,20 @@ extern "C" int nerf_mlp_fp32_bwd(int64_t M, int cp, int cv, const nerf_fp32_laye
             w.out = L.out_features; w.in = G.cols[s];
             w.out_pad = (w.out + 31) / 32 * 32; w.in_pad = (L.k_padded[s] + 31) / 32 * 32;
             NERF_REQUIRE(w.in_pad / 32 <= 4 * WG_MAX_COL_TILES, NERF_E_ARCH);
-            const int chunks = wgrad_chunks(w.steps, w.out_pad / 32);
+            const int chunks = prog::wgrad_chunks(w.steps, w.out_pad / 32);
             w.part = part;
             w.part_bias = part + (int64_t)chunks * w.out_pad * w.in_pad;
-            hipLaunchKernelGGL(fp32_wgrad_kernel, dim3(w.out_pad / 32, chunks), dim3(256), 0, st, w);
+            hipLaunchKernelGGL(fp32_wgrad_kernel, dim3(chunks, w.out_pad / 32), dim3(256), 0, st, w);
             rc = nerf_launch_status();
             if (rc) return rc;
-            WgradReduceArgs r{};
+            prog::WgradReduceArgs r{};
             r.part = w.part; r.part_bias = w.part_bias; r.n_chunks = chunks; r.out = w.out; r.in = w.in;
             r.out_pad = w.out_pad; r.in_pad = w.in_pad;
             r.d_weight = G.d_weight; r.ld = G.ld; r.col0 = G.col0[s];
             r.d_bias = s == 0 ? G.d_bias : nullptr;
+            r.scale = nullptr;
             const int64_t outputs = (int64_t)w.out * w.in + w.out;
-            hipLaunchKernelGGL(fp32_wgrad_reduce_kernel, dim3((unsigned)((outputs + 255) / 256)), dim3(256), 0, st, r);
+            hipLaunchKernelGGL(prog::wgrad_reduce_kernel<0>, dim3((unsigned)((outputs + 255) / 256)), dim3(256), 0, st, r);
             rc = nerf_launch_status();
             if (rc) return rc;
         }

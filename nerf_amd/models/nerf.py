@@ -71,11 +71,12 @@ class NeRF(nn.Module):
     use_viewdirs=True, or with use_viewdirs=False (the script default).
 
     ``precision`` selects the MFMA operand type ('bf16' or 'fp16'); accumulation is fp32.
-    ``precision='fp32'`` is the validation mode: an fp32-operand MFMA kernel evaluates the layers (any
-    depth, width up to 256, any skips; ``fp32_kernel_supported()``), its gradients come from library
-    GEMMs under autograd; the encodings and compositing around it are the same HIP kernels.  An
-    architecture outside the fused 16-bit kernels runs in that fp32 mode whatever ``precision`` says
-    (``effective_precision()`` reports it).
+    ``precision='fp32'`` is the validation mode (exact fp32 products).  Every other architecture the
+    constructor accepts (any depth, width up to 256, any skips; ``program_supported()``) runs on the
+    program-driven kernels -- the network handed over as a list of layers -- in the requested operand type:
+    forward, backward-data chain and weight gradients are this library's MFMA kernels there as well.  Beyond
+    those limits the layers are evaluated by library GEMMs in fp32 (``effective_precision()`` reports it).
+    The encodings and compositing around the MLP are the same HIP kernels in every mode.
     """
 
     def __init__(self, D: int = 8, W: int = 256, input_ch_pts: int = 63, input_ch_views: int = 27,
@@ -114,8 +115,9 @@ class NeRF(nn.Module):
         return self.precision in _FUSED_PRECISIONS and self.kernel_supported()
 
     def effective_precision(self) -> str:
-        """The precision calls actually run in: ``precision``, or 'fp32' for an architecture outside the fused kernels."""
-        return self.precision if self.fused() else "fp32"
+        """The operand type calls actually run in: ``precision`` on the fused kernels and on the layer-program
+        kernels, 'fp32' where only library GEMMs cover the architecture."""
+        return self.precision if (self.fused() or self.program_supported()) else "fp32"
 
     def _require_supported(self):
         if not self.kernel_supported():
@@ -170,7 +172,7 @@ class NeRF(nn.Module):
         if self.use_viewdirs and x_views_encoded is None:
             raise ValueError("View directions (x_views_encoded) must be provided when use_viewdirs is True.")
         if not self.fused():
-            return self._forward_fp32(x_pts_encoded, x_views_encoded)
+            return self._forward_program(x_pts_encoded, x_views_encoded)
         if not self.use_viewdirs:
             x_views_encoded = None          # ignored, as nerf.py:202-206 does
         if x_pts_encoded.shape[-1] != 63 or (x_views_encoded is not None and x_views_encoded.shape[-1] != 27):
@@ -183,32 +185,44 @@ class NeRF(nn.Module):
                                      self.ordered_params(), viewdirs=self.use_viewdirs)
 
 
-    # -- fp32 validation mode -----------------------------------------------------------------
-    def fp32_kernel_supported(self) -> bool:
-        """True when the fp32 MFMA kernel covers this architecture (its LDS-resident activations bound the
-        widths; a skip connection after the last hidden layer is not a network the reference can run)."""
+    # -- layer-program kernels: fp32 validation mode, and 16-bit operands outside the fused architectures ----
+    def program_supported(self) -> bool:
+        """True when the layer-program MFMA kernels cover this architecture (their LDS-resident activations
+        bound the widths; a skip connection after the last hidden layer is not a network the reference can run)."""
         n_layers = self.D + (4 if self.use_viewdirs else 1)
         return (1 <= self.W <= _C.FP32_MAX_WIDTH and 1 <= self.input_ch_pts <= _C.FP32_MAX_PTS
                 and (not self.use_viewdirs or 1 <= self.input_ch_views <= _C.FP32_MAX_VIEWS)
                 and n_layers <= _C.FP32_MAX_LAYERS and all(0 <= i < self.D - 1 for i in self.skips))
 
-    def _fp32_program(self):
-        """The layer list of the fp32 kernel for the current weights: (ctypes array, tensors it points to).
-        Cached under no_grad like the 16-bit weight streams; rebuilt on every call while training."""
+    fp32_kernel_supported = program_supported
+
+    def program_mode(self) -> str:
+        """Operand type of the layer-program kernels for this network: ``precision``."""
+        if self.precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {_PRECISIONS}, got {self.precision!r}")
+        return self.precision
+
+    def _layer_program(self, mode: str):
+        """The layer list of the program kernels for the current weights in operand type ``mode``: (ctypes
+        array, tensors it points to, per-layer description).  Cached under no_grad like the fused kernels'
+        weight streams; rebuilt on every call while training."""
         ps = self.ordered_params()
         training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
-        key = None if training else ("fp32",) + tuple((p.data_ptr(), p._version) for p in ps)
+        key = None if training else ("program", mode) + tuple((p.data_ptr(), p._version) for p in ps)
         if not training and key == self._pack_key and self._fp32_prog is not None:
             return self._fp32_prog
         keep, layers, spec = [], [], []
-        pad8 = lambda v: (v + 7) // 8 * 8
+        kpad = 8 if mode == "fp32" else 16          # input features per weight chunk of the kernel
+        pad8 = lambda v: (v + kpad - 1) // kpad * kpad
+        pack = (lambda w, c0, c: ops.fp32_pack_segment(w, c0, c)) if mode == "fp32" else \
+               (lambda w, c0, c: ops.p16_pack_segment(w, c0, c, mode))
 
         def add(lin, segments, relu, dst, dst_col=0):
             spec.append((lin, segments, dst, dst_col))
             L = _C.Fp32Layer()
             L.n_segments = len(segments)
             for s, (col0, cols, src) in enumerate(segments):
-                w = ops.fp32_pack_segment(lin.weight, col0, cols)
+                w = pack(lin.weight, col0, cols)
                 keep.append(w)
                 L.weights[s], L.k_padded[s], L.src[s] = w.data_ptr(), pad8(cols), src
             b = lin.bias.detach().contiguous()
@@ -240,11 +254,13 @@ class NeRF(nn.Module):
         return self._fp32_prog
 
     @staticmethod
-    def _fp32_transposed_weights(spec):
-        """Per layer and segment of ``spec`` (from ``_fp32_program``) the packed TRANSPOSED weight block the
+    def _transposed_weights(spec, mode: str):
+        """Per layer and segment of ``spec`` (from ``_layer_program``) the packed TRANSPOSED weight block the
         backward-data chain multiplies with, or None for a segment read from the encoded inputs (nothing flows back
         there): the [cols, out] matrix W[:, col0:col0+cols]^T, for a layer that writes raw placed in columns
         dst_col.. of a [cols, 4] matrix (the chain reads d_raw [M, 4] as that layer's output gradient)."""
+        pack = (lambda w, c0, c: ops.fp32_pack_segment(w, c0, c)) if mode == "fp32" else \
+               (lambda w, c0, c: ops.p16_pack_segment(w, c0, c, mode))
         out = []
         with torch.no_grad():
             for lin, segments, dst, dst_col in spec:
@@ -257,28 +273,28 @@ class NeRF(nn.Module):
                     if dst == _C.FP32_DST_RAW:
                         full = torch.zeros((cols, 4), dtype=torch.float32, device=wt.device)
                         full[:, dst_col:dst_col + lin.out_features] = wt
-                        per_seg.append(ops.fp32_pack_segment(full, 0, 4))
+                        per_seg.append(pack(full, 0, 4))
                     else:
-                        per_seg.append(ops.fp32_pack_segment(wt.contiguous(), 0, lin.out_features))
+                        per_seg.append(pack(wt.contiguous(), 0, lin.out_features))
                 out.append(per_seg)
         return out
 
-    def _forward_fp32(self, x_pts_encoded: torch.Tensor, x_views_encoded: Optional[torch.Tensor]) -> torch.Tensor:
-        """fp32 evaluation of nerf.py:173-209 (validation mode, any architecture): the fp32 MFMA kernel
-        where it covers the architecture, else layer-by-layer library GEMMs."""
+    def _forward_program(self, x_pts_encoded: torch.Tensor, x_views_encoded: Optional[torch.Tensor]) -> torch.Tensor:
+        """nerf.py:173-209 for any architecture: the layer-program MFMA kernels in the operand type of
+        ``precision`` where they cover the architecture, else layer-by-layer library GEMMs in fp32."""
         if x_pts_encoded.shape[-1] != self.input_ch_pts:
             raise ValueError(f"expected encoded points of width {self.input_ch_pts}, got {x_pts_encoded.shape[-1]}")
         if not self.use_viewdirs:
             x_views_encoded = None
         elif x_views_encoded.shape[-1] != self.input_ch_views:
             raise ValueError(f"expected encoded view directions of width {self.input_ch_views}, got {x_views_encoded.shape[-1]}")
-        if not self.fp32_kernel_supported():
+        if not self.program_supported():
             return self._forward_library(x_pts_encoded, x_views_encoded, None)
         lead = x_pts_encoded.shape[:-1]
         xp = x_pts_encoded.reshape(-1, self.input_ch_pts)
         xv = None if x_views_encoded is None else x_views_encoded.reshape(-1, self.input_ch_views)
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        raw = _Fp32Forward.apply(self, xp, xv, want_grad, *self.ordered_params())
+        raw = _ProgramForward.apply(self, xp, xv, want_grad, self.program_mode(), *self.ordered_params())
         return raw.view(*lead, 4)
 
     def _forward_library(self, x_pts_encoded, x_views_encoded, params) -> torch.Tensor:
@@ -301,34 +317,42 @@ class NeRF(nn.Module):
         return torch.cat((rgb, sigma), dim=-1)
 
 
-class _Fp32Forward(torch.autograd.Function):
-    """Forward and parameter gradients: the fp32 MFMA kernels of this library (nerf_mlp_fp32_fwd_train keeps the
-    activations, nerf_mlp_fp32_bwd runs the backward-data chain and the weight-gradient contractions).  Only when
-    a gradient with respect to the encoded inputs is asked for -- which the reference's scripts never do -- are
-    the layers evaluated again with library GEMMs under autograd and differentiated there."""
+class _ProgramForward(torch.autograd.Function):
+    """Forward and parameter gradients on the layer-program MFMA kernels of this library, in fp32 or with 16-bit
+    operands (nerf_mlp_fp32_* / nerf_mlp_p16_*: the training forward keeps the activations, the backward runs the
+    backward-data chain and the weight-gradient contractions).  Only when a gradient with respect to the encoded
+    inputs is asked for -- which the reference's scripts never do -- are the layers evaluated again with library
+    GEMMs (fp32) under autograd and differentiated there."""
+
+    N_FIXED = 5          # arguments in front of the parameters
 
     @staticmethod
-    def forward(ctx, model, x_pts, x_views, want_grad, *params):
-        layers, _keep, spec = model._fp32_program()
-        ctx.model = model
+    def forward(ctx, model, x_pts, x_views, want_grad, mode, *params):
+        layers, _keep, spec = model._layer_program(mode)
+        ctx.model, ctx.mode = model, mode
         ctx.has_views = x_views is not None
         need_inputs = ctx.needs_input_grad[1] or (x_views is not None and ctx.needs_input_grad[2])
         # (needs_input_grad is set for parameters under no_grad as well: the caller says whether a graph is recorded)
-        ctx.kernel_backward = want_grad and any(ctx.needs_input_grad[4:]) and not need_inputs
+        ctx.kernel_backward = want_grad and any(ctx.needs_input_grad[_ProgramForward.N_FIXED:]) and not need_inputs
         if ctx.kernel_backward:
-            raw, ctx.acts = ops.fp32_mlp_forward_train(x_pts, x_views, layers)
+            if mode == "fp32":
+                raw, ctx.acts = ops.fp32_mlp_forward_train(x_pts, x_views, layers)
+            else:
+                raw, ctx.acts = ops.p16_mlp_forward_train(x_pts, x_views, layers, mode)
             ctx.layers, ctx.keep, ctx.spec = layers, _keep, spec
-            ctx.wt = NeRF._fp32_transposed_weights(spec)       # of the weights this forward used
+            ctx.wt = NeRF._transposed_weights(spec, mode)       # of the weights this forward used
             ctx.param_ids = [id(p) for p in model.ordered_params()]
             ctx.M, ctx.cp = x_pts.shape[0], x_pts.shape[1]
             ctx.cv = x_views.shape[1] if x_views is not None else 0
         else:
-            raw = ops.fp32_mlp_forward(x_pts, x_views, layers)
+            raw = ops.fp32_mlp_forward(x_pts, x_views, layers) if mode == "fp32" else \
+                ops.p16_mlp_forward(x_pts, x_views, layers, mode)
             ctx.save_for_backward(x_pts, *([x_views] if x_views is not None else []), *params)
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
+        nf = _ProgramForward.N_FIXED
         if ctx.kernel_backward:
             n_par = len(ctx.param_ids)
             grads_out = [None] * n_par
@@ -343,15 +367,18 @@ class _Fp32Forward(torch.autograd.Function):
                     G.wt[s] = None if wt is None else wt.data_ptr()
                 grads_out[ctx.param_ids.index(id(lin.weight))] = dw
                 grads_out[ctx.param_ids.index(id(lin.bias))] = db
-            ops.fp32_mlp_backward(ctx.M, ctx.cp, ctx.cv, ctx.layers, arr, d_raw.reshape(ctx.M, 4), ctx.acts)
+            if ctx.mode == "fp32":
+                ops.fp32_mlp_backward(ctx.M, ctx.cp, ctx.cv, ctx.layers, arr, d_raw.reshape(ctx.M, 4), ctx.acts)
+            else:
+                ops.p16_mlp_backward(ctx.M, ctx.cp, ctx.cv, ctx.layers, arr, d_raw.reshape(ctx.M, 4), ctx.acts, ctx.mode)
             ctx.acts = None
-            need = ctx.needs_input_grad[4:]
-            return (None, None, None, None, *[g if n else None for g, n in zip(grads_out, need)])
+            need = ctx.needs_input_grad[nf:]
+            return (*([None] * nf), *[g if n else None for g, n in zip(grads_out, need)])
         saved = ctx.saved_tensors
         x_pts = saved[0]
         x_views = saved[1] if ctx.has_views else None
         params = saved[2 if ctx.has_views else 1:]
-        need = list(ctx.needs_input_grad[1:3]) + list(ctx.needs_input_grad[4:])          # x_pts, x_views, params...
+        need = list(ctx.needs_input_grad[1:3]) + list(ctx.needs_input_grad[nf:])          # x_pts, x_views, params...
         with torch.enable_grad():
             xp = x_pts.detach().requires_grad_(need[0])
             xv = None if x_views is None else x_views.detach().requires_grad_(need[1])
@@ -360,7 +387,7 @@ class _Fp32Forward(torch.autograd.Function):
             wanted = [t for t, n in zip([xp, xv] + ps, need) if n and t is not None]
             got = iter(torch.autograd.grad(raw, wanted, d_raw.contiguous(), allow_unused=True)) if wanted else iter(())
         out = [next(got) if (n and t is not None) else None for t, n in zip([xp, xv] + ps, need)]
-        return (None, out[0], out[1], None, *out[2:])
+        return (None, out[0], out[1], None, None, *out[2:])
 
 
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, N_samples: int, det: bool = False, *,

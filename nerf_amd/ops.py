@@ -636,6 +636,81 @@ def fp32_mlp_backward(M: int, cp: int, cv: int, layers, grads, d_raw: torch.Tens
 
 
 # ---------------------------------------------------------------------------
+# 16-bit-operand layer programs (any architecture within the program's limits, precision 'bf16' / 'fp16')
+# ---------------------------------------------------------------------------
+
+def p16_pack_segment(weight: torch.Tensor, col0: int, cols: int, precision: str) -> torch.Tensor:
+    """Columns [col0, col0+cols) of a [rows, ld] weight matrix in the fragment order of the 16-bit program kernel."""
+    w = _gpu_f32(weight.detach(), "weight")
+    rows, ld = w.shape
+    out = torch.empty((int(lib.nerf_mlp_p16_segment_bytes(rows, cols)),), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        check(lib.nerf_mlp_p16_pack_segment(_p(w), rows, ld, int(col0), int(cols), _C.PREC[precision], _p(out),
+                                            _stream(w.device)), "nerf_mlp_p16_pack_segment")
+    return out
+
+
+def _encoded_pair(x_pts, x_views):
+    xp = _gpu_f32(x_pts, "x_pts_encoded")
+    M, cp = xp.shape
+    xv, cv = None, 0
+    if x_views is not None:
+        xv = _gpu_f32(x_views, "x_views_encoded")
+        if xv.shape[0] != M:
+            raise ValueError("x_pts_encoded and x_views_encoded must have the same number of rows")
+        cv = xv.shape[1]
+    return xp, xv, M, cp, cv
+
+
+def p16_mlp_forward(x_pts: torch.Tensor, x_views: Optional[torch.Tensor], layers, precision: str) -> torch.Tensor:
+    """raw [M, 4] of the network ``layers`` describes (``_C.Fp32Layer`` array whose weights were packed by
+    ``p16_pack_segment``) with 16-bit operands."""
+    xp, xv, M, cp, cv = _encoded_pair(x_pts, x_views)
+    raw = torch.empty((M, 4), dtype=torch.float32, device=xp.device)
+    with torch.cuda.device(xp.device), _timed("mlp_fwd_p16", xp.device, M):
+        check(lib.nerf_mlp_p16_fwd(M, _p(xp), cp, _p(xv), cv, ctypes.cast(layers, ctypes.c_void_p), len(layers),
+                                   _C.PREC[precision], _p(raw), _stream(xp.device)), "nerf_mlp_p16_fwd")
+    return raw
+
+
+def p16_mlp_forward_train(x_pts: torch.Tensor, x_views: Optional[torch.Tensor], layers, precision: str):
+    """``p16_mlp_forward`` that also keeps the encoded inputs and every hidden layer's output (in the operand
+    type) for ``p16_mlp_backward``: returns (raw [M, 4], saved)."""
+    xp, xv, M, cp, cv = _encoded_pair(x_pts, x_views)
+    lp = ctypes.cast(layers, ctypes.c_void_p)
+    n_saved = int(lib.nerf_mlp_p16_saved_bytes(M, cp, cv, lp, len(layers)))
+    if n_saved < 0:
+        raise ValueError("p16_mlp_forward_train: bad layer list")
+    raw = torch.empty((M, 4), dtype=torch.float32, device=xp.device)
+    saved = torch.empty((max(n_saved, 16),), dtype=torch.uint8, device=xp.device)
+    with torch.cuda.device(xp.device), _timed("mlp_fwd_p16_train", xp.device, M):
+        check(lib.nerf_mlp_p16_fwd_train(M, _p(xp), cp, _p(xv), cv, lp, len(layers), _C.PREC[precision], _p(raw), _p(saved),
+                                         _stream(xp.device)), "nerf_mlp_p16_fwd_train")
+    return raw, saved
+
+
+def p16_mlp_backward(M: int, cp: int, cv: int, layers, grads, d_raw: torch.Tensor, saved: torch.Tensor,
+                     precision: str) -> None:
+    """Weight and bias gradients of the network ``layers`` describes into the tensors ``grads`` (``_C.Fp32Grad``
+    array) points to, from ``d_raw`` [M, 4] and what ``p16_mlp_forward_train`` kept.  In fp16 the gradients are
+    scaled by a power of two that puts max|d_raw| near 2^10 and scaled back at the end."""
+    d_raw = _gpu_f32(d_raw, "d_raw")
+    if tuple(d_raw.shape) != (M, 4):
+        raise ValueError(f"d_raw must be [{M}, 4], got {tuple(d_raw.shape)}")
+    dev = d_raw.device
+    scale = None
+    if precision == "fp16" and M > 0:
+        amax = d_raw.abs().amax().clamp_min(1e-30)
+        scale = torch.exp2(torch.floor(torch.log2(1024.0 / amax)).clamp(-24.0, 24.0)).reshape(1)
+    lp, gp = ctypes.cast(layers, ctypes.c_void_p), ctypes.cast(grads, ctypes.c_void_p)
+    n_work = int(lib.nerf_mlp_p16_bwd_workspace_bytes(M, cp, cv, lp, len(layers)))
+    work = torch.empty((max(n_work, 256),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("mlp_bwd_p16", dev, M):
+        check(lib.nerf_mlp_p16_bwd(M, cp, cv, lp, gp, len(layers), _C.PREC[precision], _p(d_raw), _p(saved), _p(scale),
+                                   _p(work), work.numel(), _stream(dev)), "nerf_mlp_p16_bwd")
+
+
+# ---------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------
 

@@ -61,6 +61,62 @@ for M in ms:
         assert rc == -5, (M, archs, rc)
         calls += 3
     assert lib.nerf_mlp_bwd(M, FAKE, FAKE, 0, FAKE, None, FAKE, wb - 1, FAKE, None) == -5
+# layer-program kernels (fp32 and 16-bit operands): sizing and the backward's host-side program construction, stopped
+# by the workspace check, for a network with a skip connection and the colour head
+
+
+class Layer(ctypes.Structure):         # nerf_fp32_layer_t
+    _fields_ = [("weights", c_void_p * 2), ("k_padded", c_int * 2), ("src", c_int * 2), ("n_segments", c_int),
+                ("bias", c_void_p), ("out_features", c_int), ("relu", c_int), ("dst", c_int), ("dst_col", c_int)]
+
+
+class Grad(ctypes.Structure):          # nerf_fp32_grad_t
+    _fields_ = [("wt", c_void_p * 2), ("d_weight", c_void_p), ("ld", c_int), ("col0", c_int * 2), ("cols", c_int * 2),
+                ("d_bias", c_void_p)]
+
+
+PTS, VIEWS, A, B, RAW = 0, 1, 2, 3, 4
+for fam, kpad, unit in (("fp32", 8, "floats"), ("p16", 16, "bytes")):
+    pad = lambda v: (v + kpad - 1) // kpad * kpad      # noqa: E731
+    W, CP, CV = 100, 63, 27
+    # (segments [(cols, src)], out, relu, dst, dst_col)
+    net = [([(CP, PTS)], W, 1, A, 0), ([(CP, PTS), (W, A)], W, 1, B, 0), ([(W, B)], 1, 0, RAW, 3), ([(W, B)], W, 0, A, 0),
+           ([(W, A), (CV, VIEWS)], W // 2, 1, B, 0), ([(W // 2, B)], 3, 0, RAW, 0)]
+    layers, grads = (Layer * len(net))(), (Grad * len(net))()
+    for L, G, (segs, out, relu, dst, col) in zip(layers, grads, net):
+        L.n_segments = len(segs)
+        c0 = 0
+        for s, (cols, src) in enumerate(segs):
+            L.weights[s], L.k_padded[s], L.src[s] = FAKE, pad(cols), src
+            G.wt[s], G.col0[s], G.cols[s] = (FAKE if src in (A, B) else None), c0, cols
+            c0 += cols
+        L.bias, L.out_features, L.relu, L.dst, L.dst_col = FAKE, out, relu, dst, col
+        G.d_weight, G.d_bias, G.ld = FAKE, FAKE, c0
+    lp, gp = ctypes.cast(layers, c_void_p), ctypes.cast(grads, c_void_p)
+    saved_fn, work_fn = getattr(lib, f"nerf_mlp_{fam}_saved_{unit}"), getattr(lib, f"nerf_mlp_{fam}_bwd_workspace_{unit}")
+    for fn in (saved_fn, work_fn):
+        fn.restype = c_int64
+        fn.argtypes = [c_int64, c_int, c_int, c_void_p, c_int]
+    bwd = getattr(lib, f"nerf_mlp_{fam}_bwd")
+    bwd.restype = c_int
+    if fam == "fp32":
+        bwd.argtypes = [c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+    else:
+        bwd.argtypes = [c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                        c_void_p]
+    tile, esz = (64, 1) if fam == "fp32" else (128, 2)
+    rows = pad(CP) + pad(CV) + 3 * W + W // 2
+    for M in ms[::7]:
+        ldm = (M + tile - 1) // tile * tile
+        assert saved_fn(M, CP, CV, lp, len(net)) == rows * ldm * esz, (fam, M)
+        need = work_fn(M, CP, CV, lp, len(net))
+        assert need > (kpad + 3 * W + W // 2) * ldm * esz, (fam, M, need)
+        if fam == "fp32":
+            rc = bwd(M, CP, CV, lp, gp, len(net), FAKE, FAKE, FAKE, need - 1, None)
+        else:
+            rc = bwd(M, CP, CV, lp, gp, len(net), M % 2, FAKE, FAKE, None, FAKE, need - 1, None)
+        assert rc == -5, (fam, M, rc)
+        calls += 1
 # argument errors
 nets = (WgradNet * 2)()
 nets[0].M, nets[1].M = 100, 100

@@ -135,6 +135,64 @@ def test_fp32_backward_arguments_are_validated_on_the_host():
     assert call(130, FAKE, need) == -4
 
 
+def test_p16_program_arguments_are_validated_on_the_host():
+    """The 16-bit layer-program entry points: the same layer lists with input features padded to 16, sizes in bytes,
+    and the operand type checked before anything else."""
+    from nerf_amd import _C
+    lib = ctypes.CDLL(LIB)
+    i64, i32, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+    lib.nerf_mlp_p16_fwd.restype = i32
+    lib.nerf_mlp_p16_fwd.argtypes = [i64, vp, i32, vp, i32, vp, i32, i32, vp, vp]
+    lib.nerf_mlp_p16_bwd.restype = i32
+    lib.nerf_mlp_p16_bwd.argtypes = [i64, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp]
+    lib.nerf_mlp_p16_segment_bytes.restype = i64
+    lib.nerf_mlp_p16_segment_bytes.argtypes = [i32, i32]
+    lib.nerf_mlp_p16_pack_segment.restype = i32
+    lib.nerf_mlp_p16_pack_segment.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    for fn in (lib.nerf_mlp_p16_saved_bytes, lib.nerf_mlp_p16_bwd_workspace_bytes):
+        fn.restype = i64
+        fn.argtypes = [i64, i32, i32, vp, i32]
+    FAKE = 0x10000
+    A, RAW, PTS = _C.FP32_BUF_A, _C.FP32_DST_RAW, _C.FP32_BUF_PTS
+    assert lib.nerf_mlp_p16_segment_bytes(100, 63) == 4 * 4 * 1024            # 4 row tiles x 4 chunks of 16 inputs
+    assert lib.nerf_mlp_p16_segment_bytes(0, 63) == 0
+    assert lib.nerf_mlp_p16_pack_segment(FAKE, 100, 63, 0, 63, 7, FAKE, None) == -6      # unknown operand type
+    assert lib.nerf_mlp_p16_pack_segment(FAKE, 100, 63, 1, 63, 0, FAKE, None) == -2      # columns beyond the row
+    layers = (_C.Fp32Layer * 2)()
+    grads = (_C.Fp32Grad * 2)()
+    for L, (k, src, out, dst) in zip(layers, ((64, PTS, 100, A), (112, A, 4, RAW))):
+        L.n_segments = 1
+        L.weights[0], L.k_padded[0], L.src[0] = FAKE, k, src
+        L.bias, L.out_features, L.relu, L.dst, L.dst_col = FAKE, out, 1, dst, 0
+    for G, (ld, cols) in zip(grads, ((63, 63), (100, 100))):
+        G.d_weight, G.d_bias, G.ld = FAKE, FAKE, ld
+        G.col0[0], G.cols[0] = 0, cols
+    grads[1].wt[0] = FAKE
+    lp, gp = ctypes.cast(layers, vp), ctypes.cast(grads, vp)
+    fwd = lambda prec: lib.nerf_mlp_p16_fwd(64, FAKE, 63, None, 0, lp, 2, prec, FAKE, None)   # noqa: E731
+    assert fwd(2) == -6
+    layers[1].k_padded[0] = 104                           # a multiple of 8 is not enough here
+    assert fwd(0) == -4
+    layers[1].k_padded[0] = 144                           # A holds 128 features (4 row tiles)
+    assert fwd(0) == -4
+    layers[1].k_padded[0] = 112
+    rows = 64 + 0 + 100                                   # padded points, no views, one hidden layer
+    assert lib.nerf_mlp_p16_saved_bytes(130, 63, 0, lp, 2) == rows * 256 * 2       # 130 samples -> 2 tiles of 128
+    need = lib.nerf_mlp_p16_bwd_workspace_bytes(130, 63, 0, lp, 2)
+    assert need > (16 + 100) * 256 * 2 and need % 4 == 0
+    call = lambda M, ws, n, prec=1: lib.nerf_mlp_p16_bwd(M, 63, 0, lp, gp, 2, prec, FAKE, FAKE, None, ws, n, None)   # noqa: E731
+    assert call(-1, FAKE, need) == -2
+    assert call(130, FAKE, need, 5) == -6
+    assert call(130, FAKE, need - 1) == -5                # workspace too small
+    assert call(130, None, need) == -1
+    assert call(130, FAKE + 16, need) == -3               # 256-byte alignment
+    grads[1].wt[0] = None                                 # a hidden source needs its transposed weights
+    assert call(130, FAKE, need) == -1
+    grads[1].wt[0] = FAKE
+    grads[0].cols[0] = 40                                 # does not round up to the layer's k_padded
+    assert call(130, FAKE, need) == -4
+
+
 def test_cpu_tensors_are_rejected():
     """the kernels have no CPU path: CPU tensors raise before reaching the library (get_rays alone serves a pose
     in host memory, with torch CPU ops, as the reference's loader workers need)"""

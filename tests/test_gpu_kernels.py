@@ -378,9 +378,10 @@ def test_mlp_forward_golden(amd, golden, precision):
 
 def test_mlp_other_architectures_run(amd, golden):
     """Architectures outside the fused kernels (the reference's own test shape, tests/test_nerf_model.py:105-109:
-    D=4, W=64, skips=[2]) run layer by layer in fp32 whatever `precision` says."""
+    D=4, W=64, skips=[2]) run on the layer-program kernels in the requested operand type (test_gpu_p16.py,
+    test_gpu_fp32.py); beyond those kernels' widths the layers are library GEMMs in fp32, and the model says so."""
     g = golden("f3_mlp")
-    m = amd_model(O.init_params(2, D=4, W=64, skips=(2,)), "bf16", D=4, W=64, skips=[2])
+    m = amd_model(O.init_params(2, D=4, W=64, skips=(2,)), "fp32", D=4, W=64, skips=[2])
     assert m.pts_linears[3].in_features == 64 + 63
     assert not m.fused() and m.effective_precision() == "fp32"
     ep = O.positional_encode(T(g["pts"])[:512], 10).to(DEV)
@@ -389,6 +390,12 @@ def test_mlp_other_architectures_run(amd, golden):
         assert maxabs(m(ep, ev), T(g["raw_mini"])) < 2e-5
     with pytest.raises(NotImplementedError):
         m.forward_rays(torch.zeros(8, 3, device=DEV), torch.zeros(8, 3, device=DEV), torch.zeros(8, 4, device=DEV))
+    assert amd_model(O.init_params(2, D=4, W=64, skips=(2,)), "bf16", D=4, W=64, skips=[2]).effective_precision() == "bf16"
+    wide = amd.NeRF(D=2, W=320, skips=[], precision="bf16").to(DEV)
+    assert not wide.program_supported() and wide.effective_precision() == "fp32"
+    with torch.no_grad():
+        x, v = torch.randn(10, 63, device=DEV), torch.randn(10, 27, device=DEV)
+        assert maxabs(wide(x, v), wide._forward_library(x, v, None)) == 0.0
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])

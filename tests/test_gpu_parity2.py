@@ -142,10 +142,12 @@ def test_reference_written_checkpoint_renders_and_resumes(amd, name):
     from nerf_amd.train import TrainStep
     ck, g = _load_ref_ckpt(name)
     assert ck["epoch"] == 3 and ck["global_step"] == 2 and (ck["H"], ck["W"]) == (20, 24)
-    mc, mf, pe, pv, cfg = C.build_models(ck, device=DEV)
+    mc, mf, pe, pv, cfg = C.build_models(ck, device=DEV, precision="fp32")
     a = ck["args_saved_at_checkpoint"]
     assert (mf is not None) == a["use_hierarchical"] and (pv is not None) == a["use_viewdirs"]
     assert cfg["precision"] == "fp32" and mc.D == 4 and mc.W == 32 and pe.output_dims == 39
+    # (the default operand type, bf16, is kept for this architecture too: it runs on the layer-program kernels)
+    assert C.build_models(ck, device=DEV)[4]["precision"] == "bf16"
     ro, rd = T(g["rays_o"], DEV), T(g["rays_d"], DEV)
     nc, nf = a["N_samples_coarse"], a["N_samples_fine"]
     with torch.no_grad():
@@ -184,17 +186,19 @@ def test_checkpoint_without_viewdirs_renders_a_frame(amd):
     from nerf_amd import checkpoint as C
     from nerf_amd.render import render_image
     ck, g = _load_ref_ckpt("f10_ckpt_default_flags")
-    mc, mf, pe, pv, _ = C.build_models(ck, device=DEV)
-    assert mf is None and pv is None
     c2w = O.pose_spherical(20.0, -30.0, 4.0).to(DEV)
-    img = render_image(mc, mf, pe, pv, ck["H"], ck["W"], ck["focal"], c2w, N_samples_coarse=16, chunk=100)
-    assert img.shape == (20, 24, 3) and torch.isfinite(img).all()
     ro, rd = O.get_rays(20, 24, 30.0, c2w.cpu())
-    sd = {k: v.cpu() for k, v in mc.state_dict().items()}
-    with torch.no_grad():
-        ref = O.render_rays(sd, ro.reshape(-1, 3), rd.reshape(-1, 3), 2.0, 6.0, 16, L_pts=6, use_viewdirs=False, D=4,
-                            skips=(2,))
-    assert maxabs(img.reshape(-1, 3), ref["rgb_map"]) < 2e-5
+    # fp32 validation mode to summation order; the default operand type (bf16, layer-program kernels) to its rounding
+    for precision, tol in (("fp32", 2e-5), ("bf16", 3e-3)):
+        mc, mf, pe, pv, cfg = C.build_models(ck, device=DEV, precision=precision)
+        assert mf is None and pv is None and cfg["precision"] == precision
+        img = render_image(mc, mf, pe, pv, ck["H"], ck["W"], ck["focal"], c2w, N_samples_coarse=16, chunk=100)
+        assert img.shape == (20, 24, 3) and torch.isfinite(img).all()
+        sd = {k: v.cpu() for k, v in mc.state_dict().items()}
+        with torch.no_grad():
+            ref = O.render_rays(sd, ro.reshape(-1, 3), rd.reshape(-1, 3), 2.0, 6.0, 16, L_pts=6, use_viewdirs=False, D=4,
+                                skips=(2,))
+        assert maxabs(img.reshape(-1, 3), ref["rgb_map"]) < tol
 
 
 @pytest.mark.parametrize("use_graph", [True, False])

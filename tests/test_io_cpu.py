@@ -93,14 +93,22 @@ def test_checkpoint_wire_format(tmp_path):
     C.save_checkpoint(p2, epoch=0, global_step=1, args={"use_viewdirs": False, "use_hierarchical": False}, H=4, W=4,
                       focal=5.0, model_coarse=nv, optimizer=torch.optim.Adam(nv.parameters()))
     m1, m2, pe, pv, cfg = C.build_models(C.load_checkpoint(p2), device="cpu")
-    # ... which the fused 16-bit kernels cover; other depths / widths run in the fp32 validation mode
+    # ... which the fused 16-bit kernels cover; other depths / widths keep the operand type (layer-program kernels)
+    # up to width 256, and run as fp32 library GEMMs beyond
     assert m2 is None and pv is None and not m1.use_viewdirs and cfg["precision"] == "bf16"
     small = NeRF(D=4, W=64, skips=[2], input_ch_views=0, use_viewdirs=False, precision="fp32")
     p3 = str(tmp_path / "small.pth")
     C.save_checkpoint(p3, epoch=0, global_step=1, args={"use_viewdirs": False, "use_hierarchical": False, "net_depth": 4,
                                                         "net_width": 64}, H=4, W=4, focal=5.0, model_coarse=small,
                       optimizer=torch.optim.Adam(small.parameters()))
-    assert C.build_models(C.load_checkpoint(p3), device="cpu")[4]["precision"] == "fp32"
+    assert C.build_models(C.load_checkpoint(p3), device="cpu")[4]["precision"] == "bf16"
+    assert C.build_models(C.load_checkpoint(p3), device="cpu", precision="fp32")[4]["precision"] == "fp32"
+    wide = NeRF(D=2, W=320, skips=[1], input_ch_views=0, use_viewdirs=False, precision="bf16")
+    p4 = str(tmp_path / "wide.pth")
+    C.save_checkpoint(p4, epoch=0, global_step=1, args={"use_viewdirs": False, "use_hierarchical": False, "net_depth": 2,
+                                                        "net_width": 320}, H=4, W=4, focal=5.0, model_coarse=wide,
+                      optimizer=torch.optim.Adam(wide.parameters()))
+    assert C.build_models(C.load_checkpoint(p4), device="cpu")[4]["precision"] == "fp32"
     torch.save({"something": 1}, str(tmp_path / "other.pth"))
     with pytest.raises(ValueError):
         C.load_checkpoint(str(tmp_path / "other.pth"))
@@ -228,7 +236,8 @@ def test_reference_checkpoint_fixture_loads_and_oracle_renders_it(name):
             assert (f[k] - T(g[f"f_{k}"])).abs().max() < 1e-4
     # build_models on the CPU: the architecture of render_nerf.py:188-252
     mc, mf, pe, pv, cfg = C.build_models(ck, device="cpu")
-    assert (mf is not None) == hier and (pv is not None) == views and cfg["precision"] == "fp32"
+    assert (mf is not None) == hier and (pv is not None) == views and cfg["precision"] == "bf16"
+    assert C.build_models(ck, device="cpu", precision="fp32")[4]["precision"] == "fp32"
 
 
 def test_wellconditioned_fixture_matches_oracle(golden):
