@@ -46,8 +46,10 @@ def shard_items(n: int, rank: int, world: int) -> range:
 
 
 def gather_rows(block: torch.Tensor, H: int, rank: int, world: int) -> torch.Tensor:
-    """all_gather of per-rank row blocks [nrows_r, W, C] into the full [H, W, C] frame (on every rank)."""
-    if world == 1:
+    """all_gather of per-rank row blocks [nrows_r, W, C] into the full [H, W, C] frame (on every rank).
+    A lone rank has nothing to gather -- unless it runs inside a process group of size one, where the collective is
+    issued all the same (that is how a one-GPU machine exercises this path on RCCL)."""
+    if world == 1 and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() == 1):
         return block
     max_rows = shard_rows(H, 0, world)[1]
     pad = torch.zeros((max_rows,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)

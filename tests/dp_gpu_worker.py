@@ -4,7 +4,9 @@ torch.distributed.run; both ranks share GPU 0 and talk over gloo).
 argv: out_dir mode [backend], mode = "same" (both ranks hold the same rays and targets) or "split" (rank 1's
 targets differ); backend "gloo" (default: both ranks share GPU 0) or "nccl" (RCCL, one GPU per rank).  Each
 rank saves its flat weights and per-step losses after three graph-replayed steps, and under nccl also a
-row-sharded, all-gathered frame.
+row-sharded, all-gathered frame.  Mode "solo" is one rank in a process group of its own (RANK=0, WORLD_SIZE=1 in
+the environment) that runs the data-parallel step -- three graphs, two asynchronous all-reduces -- and the frame's
+all_gather on that group: the way to run the collective code on RCCL with one GPU.
 """
 import os
 import sys
@@ -15,7 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from util import O, amd_model  # noqa: E402
 
 
-def run_steps(world, rank, mode, n=256, steps=3):
+def run_steps(world, rank, mode, n=256, steps=3, step_world=None):
+    """`step_world`: the world size the step is built for when it differs from the group's (the split step on a
+    lone rank); the gradient scale is then set back to the group's 1 / world."""
     import nerf_amd
     from nerf_amd.optim import FlatAdam
     from nerf_amd.train import TrainStep
@@ -28,7 +32,9 @@ def run_steps(world, rank, mode, n=256, steps=3):
     tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(7 if (mode == "split" and rank == 1) else 0)).to(dev)
     # the single-process reference keeps the per-network launches of the data-parallel step: merged launches
     # cut the sample axis differently and agree only to rounding
-    step = TrainStep(mc, mf, pe, pv, opt, n, world_size=world, use_graph=True, joint=False)
+    step = TrainStep(mc, mf, pe, pv, opt, n, world_size=step_world or world, use_graph=True, joint=False)
+    if step_world is not None:
+        opt.device_state()[4] = 1.0 / world
     step.prepare()
     torch.manual_seed(123)                  # the same jitter draws on every rank and in the single-process run
     losses = [step(ro, rd, tgt, lr=5e-4).item() for _ in range(steps)]
@@ -53,7 +59,13 @@ if __name__ == "__main__":
     backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
     from nerf_amd.parallel import init_distributed
     rank, world, _ = init_distributed(backend)
-    flat, losses = run_steps(world, rank, mode)
+    if mode == "solo":
+        import torch.distributed as dist
+        assert world == 1 and not dist.is_initialized()
+        dist.init_process_group(backend, rank=0, world_size=1)
+        flat, losses = run_steps(1, 0, "same", step_world=2)
+    else:
+        flat, losses = run_steps(world, rank, mode)
     out = {"flat": flat, "losses": losses}
     if backend == "nccl":
         out["frame"] = render_frame(rank, world).cpu()

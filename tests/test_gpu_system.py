@@ -172,6 +172,33 @@ def test_two_rank_training_step_on_one_gpu(tmp_path):
             assert a["losses"][0] == single_losses[0] and b["losses"][0] != single_losses[0]
 
 
+def test_rccl_collectives_with_one_rank(tmp_path):
+    """The data-parallel step and the sharded render on RCCL itself (backend "nccl"), with the one rank a one-GPU
+    machine allows: process-group set-up, capture of the step's three graphs while the communicator's watchdog thread
+    is alive, the two asynchronous all-reduces of the gradient halves between graph replays, Adam on the reduced
+    bucket, and the all_gather of a frame's row blocks on device tensors.  A lone rank's sum is its own gradient, so
+    the weights after three steps equal the single-process step's bit for bit, and the gathered frame the plain one."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from dp_gpu_worker import render_frame, run_steps
+    single, single_losses = run_steps(1, 0, "same")
+    frame = render_frame(0, 1).cpu()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "dp_gpu_worker.py"), str(tmp_path), "solo", "nccl"], env=env,
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = torch.load(tmp_path / "solo_rank0.pt", weights_only=True)
+    assert torch.equal(a["flat"], single) and a["losses"] == single_losses
+    assert torch.equal(a["frame"], frame)
+
+
 def test_runs_are_bit_reproducible():
     """The kernels order their LDS rings and loads with counted waits; a missed wait would show up as run-to-run
     differences.  The same seeded 300-step training run twice, and the same frame at two chunk sizes, agree
