@@ -202,12 +202,14 @@ class NeRF(nn.Module):
             raise ValueError(f"precision must be one of {_PRECISIONS}, got {self.precision!r}")
         return self.precision
 
-    def _layer_program(self, mode: str):
+    def _layer_program(self, mode: str, training: bool):
         """The layer list of the program kernels for the current weights in operand type ``mode``: (ctypes
-        array, tensors it points to, per-layer description).  Cached under no_grad like the fused kernels'
-        weight streams; rebuilt on every call while training."""
+        array, tensors it points to, per-layer description).  With ``training`` (the caller records a graph for
+        backward) the weights are packed on every call -- which also keeps the call sequence identical from step to
+        step, as HIP-graph capture of a training step relies on: a capture that hit the cache would replay stale
+        packed weights; else the program is cached and re-made only when a parameter was modified or replaced.
+        (The caller decides: inside ``autograd.Function.forward`` grad mode is always off.)"""
         ps = self.ordered_params()
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
         key = None if training else ("program", mode) + tuple((p.data_ptr(), p._version) for p in ps)
         if not training and key == self._pack_key and self._fp32_prog is not None:
             return self._fp32_prog
@@ -328,7 +330,7 @@ class _ProgramForward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x_pts, x_views, want_grad, mode, *params):
-        layers, _keep, spec = model._layer_program(mode)
+        layers, _keep, spec = model._layer_program(mode, want_grad)
         ctx.model, ctx.mode = model, mode
         ctx.has_views = x_views is not None
         need_inputs = ctx.needs_input_grad[1] or (x_views is not None and ctx.needs_input_grad[2])

@@ -219,19 +219,60 @@ def test_p16_training_step_small_network(amd, golden):
     pe, pv = amd.PositionalEncoder(3, 10).to(DEV), amd.PositionalEncoder(3, 4).to(DEV)
     arch = dict(D=4, W=64, skips=[2])
     out = {}
-    for precision in ("fp32", "bf16"):
+    for precision, use_graph in (("fp32", False), ("bf16", False), ("bf16", True)):
         mc = amd_model(O.init_params(5, D=4, W=64, skips=(2,)), precision, **arch)
         mf = amd_model(O.init_params(6, D=4, W=64, skips=(2,)), precision, **arch)
         opt = FlatAdam(list(mc.parameters()) + list(mf.parameters()), lr=5e-4)
-        step = TrainStep(mc, mf, pe, pv, opt, NT, N_samples_coarse=64, N_samples_fine=128, use_graph=False,
+        step = TrainStep(mc, mf, pe, pv, opt, NT, N_samples_coarse=64, N_samples_fine=128, use_graph=use_graph,
                          external_uniforms=True)
         step.uniforms.copy_(torch.cat([T(g[k], DEV).reshape(-1) for k in ("t_rand_coarse", "u_fine", "t_rand_fine")]))
         losses = [step(ro, rd, tgt, lr=5e-4).item() for _ in range(3)]
-        out[precision] = (losses, torch.cat([p.detach().reshape(-1) for p in mc.parameters()]).clone())
-    l32, w32 = out["fp32"]
-    l16, w16 = out["bf16"]
+        out[(precision, use_graph)] = (losses, torch.cat([p.detach().reshape(-1) for p in mc.parameters()]).clone())
+    l32, w32 = out[("fp32", False)]
+    l16, w16 = out[("bf16", False)]
     assert all(np.isfinite(l16))
     assert all(abs(a - b) < 1e-2 * b for a, b in zip(l16, l32)), (l16, l32)
     # Adam's first steps move every weight by about +-lr: a weight differs by 2 lr per step where the two gradients
     # disagree in sign, which only tiny gradients do
     assert (w16 - w32).abs().max() < 3 * 2.5 * 5e-4 and (w16 - w32).abs().mean() < 0.5 * 5e-4
+    # the same step captured into a HIP graph (weight packing, both program kernels and their torch glue replayed)
+    lg, wg = out[("bf16", True)]
+    assert lg == l16 and torch.equal(wg, w16)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_program_kernels_under_graph_replay_follow_the_weights(amd, precision):
+    """A forward + backward of a layer-program network captured into a HIP graph packs its weights inside the graph:
+    a replay after the weights changed in place (as an optimizer step inside the graph changes them) equals the eager
+    evaluation of the new weights, bit for bit."""
+    torch.manual_seed(0)
+    m = amd.NeRF(D=4, W=64, skips=[2], precision=precision).to(DEV)
+    xp, xv, cot = _inputs(m, 500, 9)
+    params = list(m.parameters())
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        out = m(xp, xv)
+        torch.autograd.backward([out], [cot])
+        return out, [p.grad for p in params]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd_bwd()
+        fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        out_g, grads_g = fwd_bwd()
+    for it in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        og, gg = out_g.clone(), [x.clone() for x in grads_g]
+        oe, ge = fwd_bwd()
+        assert torch.equal(og, oe) and all(torch.equal(a, b) for a, b in zip(gg, ge)), it
+        with torch.no_grad():
+            for p in params:
+                p.mul_(0.7)
