@@ -70,13 +70,14 @@ class NeRF(nn.Module):
     (train_nerf.py:189-200): D=8, W=256, input_ch_pts=63, skips=[4], with input_ch_views=27 and
     use_viewdirs=True, or with use_viewdirs=False (the script default).
 
-    ``precision`` selects the MFMA operand type ('bf16' or 'fp16'); accumulation is fp32.
-    ``precision='fp32'`` is the validation mode (exact fp32 products).  Every other architecture the
-    constructor accepts (any depth, width up to 256, any skips; ``program_supported()``) runs on the
-    program-driven kernels -- the network handed over as a list of layers -- in the requested operand type:
-    forward, backward-data chain and weight gradients are this library's MFMA kernels there as well.  Beyond
-    those limits the layers are evaluated by library GEMMs in fp32 (``effective_precision()`` reports it).
-    The encodings and compositing around the MLP are the same HIP kernels in every mode.
+    ``precision`` selects the MFMA operand type: 'bf16' or 'fp16' (fp32 accumulation), or 'fp32', the
+    validation mode (exact fp32 products).  The two networks above in a 16-bit type run on the fused kernels.
+    Everything else the constructor accepts -- any depth, width up to 256, any skips, and the two networks above
+    in fp32 (``program_supported()``) -- runs on the layer-program kernels, which take the network as a list of
+    layers, in the requested operand type: forward, backward-data chain and weight gradients are this library's
+    MFMA kernels there as well.  Beyond those limits the layers are evaluated by library GEMMs in fp32
+    (``effective_precision()`` reports it).  The encodings and compositing around the MLP are the same HIP
+    kernels in every mode.
     """
 
     def __init__(self, D: int = 8, W: int = 256, input_ch_pts: int = 63, input_ch_views: int = 27,
@@ -98,7 +99,7 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(W, 4)
         self._pack_key = None
         self._packed = None
-        self._fp32_prog = None
+        self._prog = None
         self._external_pack = None
 
     # -- kernel plumbing ------------------------------------------------------------------
@@ -211,8 +212,8 @@ class NeRF(nn.Module):
         (The caller decides: inside ``autograd.Function.forward`` grad mode is always off.)"""
         ps = self.ordered_params()
         key = None if training else ("program", mode) + tuple((p.data_ptr(), p._version) for p in ps)
-        if not training and key == self._pack_key and self._fp32_prog is not None:
-            return self._fp32_prog
+        if not training and key == self._pack_key and self._prog is not None:
+            return self._prog
         keep, layers, spec = [], [], []
         kpad = 8 if mode == "fp32" else 16          # input features per weight chunk of the kernel
         pad8 = lambda v: (v + kpad - 1) // kpad * kpad
@@ -250,10 +251,10 @@ class NeRF(nn.Module):
             else:
                 add(self.output_linear, [(0, W, cur)], False, _C.FP32_DST_RAW, 0)
         arr = (_C.Fp32Layer * len(layers))(*layers)
-        self._fp32_prog = (arr, keep, spec)
+        self._prog = (arr, keep, spec)
         if not training:
             self._pack_key = key
-        return self._fp32_prog
+        return self._prog
 
     @staticmethod
     def _transposed_weights(spec, mode: str):

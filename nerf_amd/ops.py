@@ -565,7 +565,7 @@ def fused_mlp_encoded(x_pts, x_views, precision: str, packed: torch.Tensor, para
 
 
 # ---------------------------------------------------------------------------
-# fp32-operand MLP forward (validation mode, any architecture within the kernel's limits)
+# fp32-operand layer programs (validation mode, any architecture within the program's limits)
 # ---------------------------------------------------------------------------
 
 def fp32_pack_segment(weight: torch.Tensor, col0: int, cols: int) -> torch.Tensor:
