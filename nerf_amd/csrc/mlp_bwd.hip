@@ -190,7 +190,7 @@ __device__ __forceinline__ void store_unit_frag(char* base, int ks0, int nks, in
     *reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off) = f;
     return;
 #endif
-    __builtin_nontemporal_store(f, reinterpret_cast<typename Prec<PREC>::frag*>(base + unit_offset(ks0, nks, n_wt, wt, ks) + lane_off));
+    unit_store(base + unit_offset(ks0, nks, n_wt, wt, ks), (uint32_t)lane_off, f);
 }
 
 // accumulator tile (gradient w.r.t. a post-ReLU activation) -> 16-bit fragments, zeroed where the

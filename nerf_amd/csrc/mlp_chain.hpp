@@ -294,6 +294,24 @@ __device__ __forceinline__ void tile_to_frags(const f32x16& acc, typename Prec<P
     }
 }
 
+// Store of one lane's 16 bytes of a streamed unit (saved activations, dZ) at the wave-uniform address `unit` plus
+// the lane's byte offset.  NERF_UNIT_STORE_POLICY selects the cache policy: 0 = non-temporal (the compiler's
+// builtin), 1 = sc1, 2 = sc0 sc1 (inline asm in the scalar-base form; experiment switches).
+#ifndef NERF_UNIT_STORE_POLICY
+#define NERF_UNIT_STORE_POLICY 0
+#endif
+template <class F>
+__device__ __forceinline__ void unit_store(char* unit, uint32_t lane_off, const F& f) {
+    static_assert(sizeof(F) == 16, "one dwordx4 per lane");
+#if NERF_UNIT_STORE_POLICY == 0
+    __builtin_nontemporal_store(f, reinterpret_cast<F*>(unit + lane_off));
+#elif NERF_UNIT_STORE_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lane_off), "v"(f), "s"(unit));
+#else
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(lane_off), "v"(f), "s"(unit));
+#endif
+}
+
 // byte offset of (tensor starting at k-step ks0, wave tile wt, k-step ks) in a unit-organised buffer
 __device__ __forceinline__ size_t unit_offset(int ks0, int nks, int64_t n_wt, int64_t wt, int ks) {
     return ((size_t)ks0 * n_wt + (size_t)wt * nks + ks) * 1024;

@@ -140,7 +140,7 @@ __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t
     *reinterpret_cast<frag*>(unit + (uint32_t)lane_off) = f;
     return;
 #endif
-    __builtin_nontemporal_store(f, reinterpret_cast<frag*>(unit + (uint32_t)lane_off));
+    unit_store(unit, (uint32_t)lane_off, f);
 }
 // one dword per lane at byte offset lane_off4 of the wave-uniform address `base`.  A plain store on purpose: the
 // sign masks of a step (75 MB at 1024 rays) then stay in the 256 MB last-level cache until the backward-data
