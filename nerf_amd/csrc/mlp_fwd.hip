@@ -130,14 +130,13 @@ __global__ __launch_bounds__(256) void encode_units_kernel(int64_t M, int64_t n_
 template <int PREC>
 __device__ __forceinline__ void save_frag(char* saved, int ks0, int nks, int64_t n_wt, int64_t wt, int ks,
                                           int lane_off, const typename Prec<PREC>::frag& f) {
-    typedef typename Prec<PREC>::frag frag;
 #ifdef NERF_ABL_STORE_LOCAL      // timing experiment only: every store of a wave goes to one L2-resident KiB
-    *reinterpret_cast<frag*>(saved + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
+    *reinterpret_cast<typename Prec<PREC>::frag*>(saved + (size_t)(blockIdx.x * 8 + (threadIdx.x >> 6)) * 1024 + lane_off) = f;
     return;
 #endif
     char* unit = saved + unit_offset(ks0, nks, n_wt, wt, ks);        // wave-uniform
 #ifdef NERF_ABL_PLAIN_STORE      // timing experiment: default cache policy instead of non-temporal
-    *reinterpret_cast<frag*>(unit + (uint32_t)lane_off) = f;
+    *reinterpret_cast<typename Prec<PREC>::frag*>(unit + (uint32_t)lane_off) = f;
     return;
 #endif
     unit_store(unit, (uint32_t)lane_off, f);

@@ -314,28 +314,40 @@ struct WgradArgs {
     float* part_bias;     // [chunks][out_pad]
 };
 
+constexpr int WG_ROW_TILES = 2;          // 32-row tiles of dW per workgroup: every input fragment a wave loads meets both
+constexpr int WG_MAX_CHUNKS = 128;       // of the sample axis (half as many workgroup rows as row tiles: twice the chunks)
 template <int PREC>
 __global__ __launch_bounds__(256) void p16_wgrad_kernel(const WgradArgs<typename Prec<PREC>::elem> a) {
     typedef typename Prec<PREC>::frag frag;
+    constexpr int RT = WG_ROW_TILES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, kk = lane >> 5;
     // chunk on the fast grid axis: workgroups are dealt to the eight XCDs round robin, so with a chunk count that is a
     // multiple of eight the row tiles of one chunk -- which all read the same input rows -- share one XCD's L2
-    const int chunk = blockIdx.x, ot = blockIdx.y, n_chunks = gridDim.x;
+    const int chunk = blockIdx.x, ot0 = blockIdx.y * RT, n_chunks = gridDim.x;
     const int n_it = a.in_pad >> 5;
     const int64_t per = (a.steps + n_chunks - 1) / n_chunks;
     const int64_t st0 = chunk * per, st1 = st0 + per < a.steps ? st0 + per : a.steps;
-    f32x16 acc[WG_MAX_COL_TILES];
+    f32x16 acc[RT][WG_MAX_COL_TILES];
 #pragma unroll
-    for (int t = 0; t < WG_MAX_COL_TILES; ++t)
+    for (int q = 0; q < RT; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    float bsum = 0.0f;
-    const int rowA = 32 * ot + i;
-    const bool validA = rowA < a.out;
+        for (int t = 0; t < WG_MAX_COL_TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.0f;
+    float bsum[RT];
     // 16-byte fragments: fragment index = sample / 8
-    const frag* pA = reinterpret_cast<const frag*>(a.At + (int64_t)(validA ? rowA : 0) * a.ldm) + 2 * kk;
+    const frag* pA[RT];
+    bool validA[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        const int rowA = 32 * (ot0 + q) + i;
+        bsum[q] = 0.0f;
+        validA[q] = rowA < a.out;
+        pA[q] = reinterpret_cast<const frag*>(a.At + (int64_t)(validA[q] ? rowA : 0) * a.ldm) + 2 * kk;
+    }
+    const bool second = 32 * (ot0 + 1) < a.out_pad;       // workgroup-uniform: the last workgroup of an odd tile count has one
     const frag* pB[WG_MAX_COL_TILES];
     bool validB[WG_MAX_COL_TILES];
 #pragma unroll
@@ -347,16 +359,18 @@ __global__ __launch_bounds__(256) void p16_wgrad_kernel(const WgradArgs<typename
     frag zero;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (typename Prec<PREC>::elem)0.0f;
-    // U steps per iteration, all their loads issued before the first MFMA: a step alone keeps 2 + 2 per column tile
-    // 16-byte loads per lane in flight, too few to cover the memory latency
+    // U steps per iteration, all their loads issued before the first MFMA: a step alone keeps too few 16-byte loads
+    // per lane in flight to cover the memory latency
     auto steps = [&](auto UC, int64_t st) {
         constexpr int U = decltype(UC)::value;
         const int64_t f4 = st * 4;            // 32 samples = 4 fragments
-        frag av[U][2], bv[WG_MAX_COL_TILES][U][2];
+        frag av[RT][U][2], bv[WG_MAX_COL_TILES][U][2];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int q = 0; q < RT; ++q)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) av[u][e] = validA ? pA[f4 + 4 * u + e] : zero;
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) av[q][u][e] = validA[q] ? pA[q][f4 + 4 * u + e] : zero;
 #pragma unroll
         for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
             if (wave + 4 * t >= n_it) continue;          // wave-uniform
@@ -367,11 +381,13 @@ __global__ __launch_bounds__(256) void p16_wgrad_kernel(const WgradArgs<typename
         }
         if (wave == 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int q = 0; q < RT; ++q)
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum += (float)av[u][e][j];
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[q] += (float)av[q][u][e][j];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -379,26 +395,33 @@ __global__ __launch_bounds__(256) void p16_wgrad_kernel(const WgradArgs<typename
             for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
                 if (wave + 4 * t >= n_it) continue;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) acc[t] = Prec<PREC>::mfma(av[u][e], bv[t][u][e], acc[t]);
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int q = 0; q < RT; ++q)
+                        if (q == 0 || second) acc[q][t] = Prec<PREC>::mfma(av[q][u][e], bv[t][u][e], acc[q][t]);
             }
     };
     int64_t st = st0;
-    for (; st + 4 <= st1; st += 4) steps(std::integral_constant<int, 4>(), st);
+    for (; st + 2 <= st1; st += 2) steps(std::integral_constant<int, 2>(), st);
     for (; st < st1; ++st) steps(std::integral_constant<int, 1>(), st);
     // accumulator register r of lane (n = lane & 31, h = lane >> 5): row 8 (r >> 2) + 4 h + (r & 3), column n
     float* part = a.part + (int64_t)chunk * a.out_pad * a.in_pad;
 #pragma unroll
-    for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
-        if (wave + 4 * t >= n_it) continue;
+    for (int q = 0; q < RT; ++q) {
+        if (q > 0 && !second) break;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * ot + 8 * (r >> 2) + 4 * kk + (r & 3);
-            part[(int64_t)row * a.in_pad + 32 * (wave + 4 * t) + i] = acc[t][r];
+        for (int t = 0; t < WG_MAX_COL_TILES; ++t) {
+            if (wave + 4 * t >= n_it) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (ot0 + q) + 8 * (r >> 2) + 4 * kk + (r & 3);
+                part[(int64_t)row * a.in_pad + 32 * (wave + 4 * t) + i] = acc[q][t][r];
+            }
         }
-    }
-    if (wave == 0) {
-        const float other = __shfl_xor(bsum, 32);
-        if (kk == 0) a.part_bias[(int64_t)chunk * a.out_pad + rowA] = bsum + other;
+        if (wave == 0) {
+            const float other = __shfl_xor(bsum[q], 32);
+            if (kk == 0) a.part_bias[(int64_t)chunk * a.out_pad + 32 * (ot0 + q) + i] = bsum[q] + other;
+        }
     }
 }
 
@@ -450,7 +473,7 @@ static int64_t bwd_workspace(int64_t M, const nerf_fp32_layer_t* layers, int n_l
     const int64_t ldm = p16_ldm(M);
     const int64_t off = (prog::grad_rows<KPAD>(layers, n_layers, nullptr) * ldm * 2 + 255) / 256 * 256;
     if (part_off) *part_off = off;
-    return off + prog::partial_floats<KPAD>(ldm, layers, n_layers) * 4;
+    return off + prog::partial_floats<KPAD>(ldm, layers, n_layers, WG_ROW_TILES, WG_MAX_CHUNKS) * 4;
 }
 
 extern "C" int64_t nerf_mlp_p16_bwd_workspace_bytes(int64_t M, int cp, int cv, const nerf_fp32_layer_t* layers, int n_layers) {
@@ -544,10 +567,11 @@ static int p16_backward(int64_t M, int cp, int cv, const nerf_fp32_layer_t* laye
             w.out = L.out_features; w.in = G.cols[s];
             w.out_pad = (w.out + 31) / 32 * 32; w.in_pad = (L.k_padded[s] + 31) / 32 * 32;
             NERF_REQUIRE(w.in_pad / 32 <= 4 * WG_MAX_COL_TILES, NERF_E_ARCH);
-            const int chunks = prog::wgrad_chunks(w.steps, w.out_pad / 32);
+            const int row_groups = (w.out_pad / 32 + WG_ROW_TILES - 1) / WG_ROW_TILES;
+            const int chunks = prog::wgrad_chunks(w.steps, row_groups, WG_MAX_CHUNKS);
             w.part = part;
             w.part_bias = part + (int64_t)chunks * w.out_pad * w.in_pad;
-            hipLaunchKernelGGL(p16_wgrad_kernel<PREC>, dim3(chunks, w.out_pad / 32), dim3(256), 0, st, w);
+            hipLaunchKernelGGL(p16_wgrad_kernel<PREC>, dim3(chunks, row_groups), dim3(256), 0, st, w);
             rc = nerf_launch_status();
             if (rc) return rc;
             prog::WgradReduceArgs r{};

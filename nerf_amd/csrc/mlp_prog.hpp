@@ -103,24 +103,26 @@ static int64_t grad_rows(const nerf_fp32_layer_t* layers, int n_layers, int64_t*
     return r;
 }
 
-// chunks of the sample axis of one weight-gradient launch: enough workgroups to fill the chip, at least four steps each
-static inline int wgrad_chunks(int64_t steps, int out_tiles) {
+// chunks of the sample axis of one weight-gradient launch over `out_tiles` workgroup rows: enough workgroups to fill
+// the chip, at least four steps each
+static inline int wgrad_chunks(int64_t steps, int out_tiles, int max_chunks = 64) {
     int64_t c = (512 + out_tiles - 1) / out_tiles;
     if (c > steps / 4) c = steps / 4;
-    if (c > 64) c = 64;
+    if (c > max_chunks) c = max_chunks;
     return c < 1 ? 1 : (int)c;
 }
 
-// floats of the partial blocks ([chunks][out_pad][in_pad] + [chunks][out_pad]) of the largest weight-gradient launch
+// floats of the partial blocks ([chunks][out_pad][in_pad] + [chunks][out_pad]) of the largest weight-gradient launch;
+// a workgroup owns `row_tiles` 32-row tiles of dW
 template <int KPAD>
-static int64_t partial_floats(int64_t ldm, const nerf_fp32_layer_t* layers, int n_layers) {
+static int64_t partial_floats(int64_t ldm, const nerf_fp32_layer_t* layers, int n_layers, int row_tiles = 1, int max_chunks = 64) {
     int64_t part = 0;
     for (int i = 0; i < n_layers; ++i) {
         const nerf_fp32_layer_t& L = layers[i];
         const int out_pad = (L.out_features + 31) / 32 * 32;
         for (int s = 0; s < L.n_segments; ++s) {
             const int in_pad = (L.k_padded[s] + 31) / 32 * 32;
-            const int64_t need = (int64_t)wgrad_chunks(ldm / 32, out_pad / 32) * out_pad * (in_pad + 1);
+            const int64_t need = (int64_t)wgrad_chunks(ldm / 32, (out_pad / 32 + row_tiles - 1) / row_tiles, max_chunks) * out_pad * (in_pad + 1);
             if (need > part) part = need;
         }
     }
