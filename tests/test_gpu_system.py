@@ -172,6 +172,35 @@ def test_two_rank_training_step_on_one_gpu(tmp_path):
             assert a["losses"][0] == single_losses[0] and b["losses"][0] != single_losses[0]
 
 
+@pytest.mark.parametrize("hier", [False, True])
+@pytest.mark.parametrize("views", [False, True])
+def test_training_step_every_flag_combination(hier, views):
+    """The four runs train_nerf.py's flags allow (--use_hierarchical x --use_viewdirs, :62, :79, :293-331): the step
+    replayed from HIP graphs with the per-network launches equals the eagerly issued step bit for bit over six steps,
+    the merged launches of the single-process step agree to rounding, and the loss falls."""
+    import nerf_amd
+    from nerf_amd.optim import FlatAdam
+    from nerf_amd.train import TrainStep
+    from nerf_amd.utils.synthetic import seed_parameters_, synthetic_rays
+    n = 512
+    ro, rd = synthetic_rays(n, DEV, seed=0)
+    tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(0)).to(DEV)
+    res = {}
+    for mode in ("graph", "eager", "graph_per_network"):
+        mc = seed_parameters_(nerf_amd.NeRF(use_viewdirs=views).to(DEV), 0)
+        mf = seed_parameters_(nerf_amd.NeRF(use_viewdirs=views).to(DEV), 1) if hier else None
+        pe = nerf_amd.PositionalEncoder(3, 10).to(DEV)
+        pv = nerf_amd.PositionalEncoder(3, 4).to(DEV) if views else None
+        opt = FlatAdam(list(mc.parameters()) + (list(mf.parameters()) if hier else []), lr=5e-4)
+        step = TrainStep(mc, mf, pe, pv, opt, n, use_graph=mode != "eager", external_uniforms=True, joint=mode == "graph")
+        step.uniforms.copy_(torch.rand(step.n_uniforms, generator=torch.Generator().manual_seed(5)).to(DEV))
+        res[mode] = ([step(ro, rd, tgt, lr=5e-4).item() for _ in range(6)], opt.flat.clone())
+    (lg, _), (le, we), (ln, wn) = res["graph"], res["eager"], res["graph_per_network"]
+    assert ln == le and torch.equal(wn, we)
+    assert all(abs(a - b) < 2e-3 * abs(b) for a, b in zip(lg, le)), (lg, le)
+    assert all(np.isfinite(le)) and le[-1] < le[0]
+
+
 def test_rccl_collectives_with_one_rank(tmp_path):
     """The data-parallel step and the sharded render on RCCL itself (backend "nccl"), with the one rank a one-GPU
     machine allows: process-group set-up, capture of the step's three graphs while the communicator's watchdog thread
