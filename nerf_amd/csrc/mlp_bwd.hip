@@ -405,7 +405,7 @@ template <int OFF>
 __device__ __forceinline__ s16x4 tr_read(uint32_t addr) {
     s16x4 r;
 #ifdef NERF_WG_NO_LDSREAD
-    r[0] = (short)addr; r[1] = (short)(addr >> 3); r[2] = (short)OFF; r[3] = 1;
+    r[0] = (short)(0x3000 | (addr & 0xff)); r[1] = (short)(0x3000 | ((addr >> 3) & 0xff)); r[2] = (short)(0x3000 | (OFF & 0xff)); r[3] = 0x3001;   // small finite values in either operand type
     asm volatile("" : "+v"(r));
     return r;
 #endif
@@ -445,6 +445,16 @@ __device__ __forceinline__ s16x8 tr_join(const TrFrag& f) {
     r[0] = f.lo[0]; r[1] = f.lo[1]; r[2] = f.lo[2]; r[3] = f.lo[3];
     r[4] = f.hi[0]; r[5] = f.hi[1]; r[6] = f.hi[2]; r[7] = f.hi[3];
     return r;
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 wg_mfma(const s16x8& a, const s16x8& b, const f32x16& c) {
+    typedef typename Prec<PREC>::frag frag;
+#ifdef NERF_WG_NO_MFMA          // timing experiment only (wrong results): the fragments are consumed, no matrix instruction runs
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
+    return Prec<PREC>::mfma(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c);
 }
 
 template <int PREC>
@@ -502,6 +512,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
                 // every stage is the same number of copies for the counted waits; it is not contracted
                 int64_t wt = wt0 + (int64_t)step * NSUB + sub;
                 if (wt >= wt1) wt = wt1 - 1;
+#ifdef NERF_WG_L2_OPERANDS      // timing experiment only (wrong results): every step copies the segment's first wave tile
+                wt = wt0;       // again, so the operands come from L2 and the time left is the step loop's own
+#endif
                 const char* src;
                 if (u < a1n) src = a1_src + (size_t)wt * a1_stride + (size_t)u * 1024;
                 else if (u < A_NKS) src = a2_src + (size_t)wt * a2_stride + (size_t)(u - a1n) * 1024;
@@ -582,7 +595,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
+                    acc[i][j] = wg_mfma<PREC>(af[i], bf[j], acc[i][j]);
         };
         constexpr int SECOND_HALF_READS = 2 * (TI + TJ) < 15 ? 2 * (TI + TJ) : 15;
         for (int step = 0; step < nsteps; ++step) {
@@ -660,7 +673,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
+                        acc[i][j] = wg_mfma<PREC>(af[i], bf[j], acc[i][j]);
                 tr_wait_all<TI, TJ, 0>(ta1, tb1);
 #pragma unroll
                 for (int i = 0; i < TI; ++i) af[i] = tr_join(ta1[i]);
@@ -674,7 +687,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const ArchTab& ta
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = Prec<PREC>::mfma(__builtin_bit_cast(frag, af[i]), __builtin_bit_cast(frag, bf[j]), acc[i][j]);
+                        acc[i][j] = wg_mfma<PREC>(af[i], bf[j], acc[i][j]);
             }
         }
         stage = stage + 1 == WG_STAGES ? 0 : stage + 1;

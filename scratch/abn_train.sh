@@ -1,8 +1,9 @@
 #!/bin/bash
-# A/B/C three builds of the library on one box (training step only): scratch/ab3_render.sh a.so b.so c.so [rounds]
+# compare N builds of the library on one box (training step only): scratch/abn_train.sh rounds a.so b.so ...
 set -e
-for r in $(seq 1 ${4:-2}); do
-  for v in $1 $2 $3; do
+R=$1; shift
+for r in $(seq 1 $R); do
+  for v in "$@"; do
     cp scratch/lib/$v nerf_amd/lib/libnerf_hip.so
     timeout -k 10 200 python bench.py --no-cpu-baseline --no-one-eighth --no-default-flags --big-batch 0 --no-render > gpurun_out/ab.log 2>gpurun_out/ab.err
     python - "$v" <<PY
